@@ -1,0 +1,192 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json's headline metric on MI355X.
+
+    metric   Mrays/s (ray = one ray segment = one world.hit call of trace_ray, render.rs:38, counted on the
+             device) and ms/frame (= ms_per_step)
+    workload scenes/benchmark.json at 1920x1080, 256 spp, depth 6, clamp 10 (BASELINE configs[1])
+    step     one whole frame: integrate + clamp + mean + sqrt gamma + RGBA8, output resident in HBM
+
+N = 1: one fused kernel per frame.  N > 1 (one process per GPU, launched by torch.distributed.run): the
+frame's 8x8-pixel tiles are dealt round-robin to the ranks, each rank integrates its tiles into a zeroed
+float4 sum buffer, the buffers are summed onto rank 0 with one RCCL reduce over xGMI, rank 0 resolves to
+RGBA8.  The total work is the fixed frame, so scaling is "strong".
+
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# algorithmic bytes per ray segment, SURVEY.md section 8(d): 96 (path state in+out) + 20 per sphere tested
+# + 32 per node + 48 per triangle (+12 per SkyMap texel); linear world of benchmark.json: 5 spheres, no nodes
+BYTES_PER_SEGMENT_C2 = 96 + 20 * 5
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--spp", type=int, default=256)
+    ap.add_argument("--scene", default=os.path.join(ROOT, "data", "scenes", "benchmark.json"))
+    ap.add_argument("--bvh", action="store_true", help="render with enable_bvh_tree=true (not the headline)")
+    ap.add_argument("--seed", type=lambda s: int(s, 0), default=0x5EED5EED5EED5EED)
+    ap.add_argument("--cpu-spp", type=int, default=24, help="spp of the bounded CPU-baseline sample")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--pmc-traffic", type=float, default=None,
+                    help="HBM bytes per launch from a separate rocprofv3 --pmc pass (profiles/), if collected")
+    return ap.parse_args()
+
+
+def cpu_baseline(scene, width, height, spp_sample, seed):
+    """The oracle ("port": C restatement, reference not runnable -- no Rust toolchain) on this host's cores."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import copy
+
+    import pyoracle
+
+    sc = copy.copy(scene)
+    sc.settings = copy.copy(scene.settings)
+    sc.settings.samples_per_pixel = spp_sample
+    cores = len(os.sched_getaffinity(0))
+    _, _, st = pyoracle.OracleScene(sc).render(width, height, seed, threads=cores, want_rgba8=True, want_mean=False)
+    return {
+        "value": round(st.segments / st.seconds / 1e6, 3), "unit": "Mrays/s", "cores": int(st.threads), "kind": "port",
+        "sample": f"full {width}x{height} frame at {spp_sample} spp (of {scene.settings.samples_per_pixel}), "
+                  f"{st.segments} segments in {st.seconds:.2f} s; C restatement of the reference "
+                  f"(reference itself not runnable: no Rust toolchain)",
+        "ms_per_frame_extrapolated": round(st.seconds * 1e3 * scene.settings.samples_per_pixel / spp_sample, 1),
+    }
+
+
+def main():
+    args = parse_args()
+    import torch
+    import torch.distributed as dist
+
+    import raytracingrust_amd as rt
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    distributed = world > 1
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if distributed:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    scene = rt.Scene.from_file(args.scene)
+    scene.settings.samples_per_pixel = args.spp
+    if args.bvh:
+        scene.settings.enable_bvh_tree = True
+    W, H = args.width, args.height
+
+    r = rt.Renderer(local_rank)
+    r.upload_scene(scene)
+    rgba8 = torch.zeros((H, W, 4), dtype=torch.uint8, device=dev)
+    accum = torch.zeros((H, W, 4), dtype=torch.float32, device=dev) if distributed else None
+    # one explicit HIP stream for kernels, torch ops and RCCL alike (a NULL stream would mean "the context's own")
+    tstream = torch.cuda.Stream(device=dev)
+    torch.cuda.synchronize()
+    torch.cuda.set_stream(tstream)
+    stream = tstream.cuda_stream
+
+    def step(i):
+        seed = args.seed + i
+        if not distributed:
+            r.render_frame_device(W, H, seed, rgba8.data_ptr(), stream)
+        else:
+            accum.zero_()
+            r.render_tiles_device(W, H, seed, rank, world, accum.data_ptr(), stream)
+            dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)
+            if rank == 0:
+                r.resolve_device(accum.data_ptr(), args.spp, W, H, rgba8.data_ptr(), 0, stream)
+
+    def fence():
+        torch.cuda.synchronize()
+        if distributed:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    fence()
+    elapsed = time.perf_counter() - t0
+
+    # device-side counters / HIP-event kernel times of the timed launches
+    ktimes = r.kernel_times_ms()[-args.steps:]
+    segs = r.segment_counts()[-args.steps:]
+    my_segments = float(segs.sum())
+    my_kernel_ms = float(ktimes.mean()) if len(ktimes) else 0.0
+    stats = r.stats()
+
+    t = torch.tensor([elapsed, my_segments, my_kernel_ms], dtype=torch.float64, device=dev)
+    if distributed:
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = t.clone()
+        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        elapsed = float(tmax[0])
+        total_segments = float(tsum[1])
+        kernel_ms = float(tmax[2])
+    else:
+        total_segments = my_segments
+        kernel_ms = my_kernel_ms
+
+    if rank == 0:
+        ms_per_step = elapsed * 1e3 / args.steps
+        mrays = total_segments / elapsed / 1e6
+        seg_per_launch = my_segments / max(args.steps, 1)  # rank 0's kernel (N=1: the whole frame)
+        pixels_per_launch = stats.primary_samples / max(args.spp, 1)
+        alg_bytes = BYTES_PER_SEGMENT_C2 * seg_per_launch + 4.0 * pixels_per_launch
+        achieved = alg_bytes / (my_kernel_ms * 1e-3) / 1e9 if my_kernel_ms > 0 else 0.0
+        out = {
+            "metric": "Mrays/s", "value": round(mrays, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {
+                "workload": f"{os.path.basename(args.scene)} {W}x{H} {args.spp}spp depth {scene.settings.max_ray_depth} "
+                            f"clamp {scene.settings.clamp_indirect:g} "
+                            f"{'BVH' if scene.settings.enable_bvh_tree else 'linear'} world",
+                "sharding": "single fused kernel" if world == 1 else f"8x8 tiles round-robin over {world} ranks + RCCL reduce",
+                "ms_per_frame": round(ms_per_step, 4),
+                "msamples_per_s": round(W * H * args.spp * args.steps / elapsed / 1e6, 2),
+                "segments_per_frame": int(total_segments / max(args.steps, 1)),
+                "kernel_ms": round(kernel_ms, 4), "vgprs": int(stats.vgprs), "lds_bytes_per_wave": int(stats.lds_bytes),
+            },
+            "roofline": {
+                "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": args.pmc_traffic,
+                "kernel": "k_render<linear spheres>" if not scene.settings.enable_bvh_tree else "k_render<bvh>",
+                "algorithmic_bytes_per_launch": int(alg_bytes), "bytes_per_segment": BYTES_PER_SEGMENT_C2,
+                "kernel_ms_hip_events": round(my_kernel_ms, 4),
+            },
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(scene, W, H, args.cpu_spp, args.seed)
+            out["config"]["gpu_over_cpu"] = round(mrays / max(out["cpu_baseline"]["value"], 1e-9), 1)
+        print(json.dumps(out), flush=True)
+    r.close()
+    if distributed:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,224 @@
+/*
+ * rtr_hip.h -- C ABI of the MI355X-native path-tracing hot loop.
+ *
+ * This is the drop-in boundary for RayTracingRust's per-pixel radiance integrator.  The reference
+ * has no FFI of its own: the seam it replaces is the Rust function
+ *
+ *     pub fn render(target: &mut RenderTarget, scene: &Scene)          lib/core/render.rs:61
+ *
+ * -- precisely its closure + rayon loop, render.rs:74-126 -- together with the data the closure
+ * reaches through the traits of lib/core/traits.rs:13-30 and BoundsCollection (lib/core/bvh.rs:18-28).
+ * A `Scene` is lowered to the plain-old-data structs below (INTEGRATION.md shows the Rust `extern "C"`
+ * block and the lowering a maintainer would add); the entry points then do what render() does:
+ *
+ *     rtr_upload_scene   <-  scene.build_bvh() (render.rs:67, scene.rs:112) + Mesh::build_bvh (mesh.rs:119):
+ *                            the reference's median-split builder re-implemented on the host, flattened
+ *                            to a linear node array + SoA leaf records in HBM
+ *     rtr_render*        <-  the per-pixel closure calculate_pixel (render.rs:75-111), trace_ray
+ *                            (render.rs:32-59), world.hit (bvh.rs:146-199 | scene.rs:141-157),
+ *                            Material::scatter (materials.rs), Background::sample (backgrounds.rs),
+ *                            clamp / mean / sqrt / RGBA8 (render.rs:95-110, color.rs:34-41)
+ *
+ * Conventions (reference conventions in brackets):
+ *   - every function returns RTR_OK or a negative rtr_status; nothing unwinds across the boundary
+ *     [the reference panics: scene.rs:75, mesh.rs:65, bvh.rs:99, render.rs:95];
+ *   - the caller owns every buffer; inputs are copied during rtr_upload_scene and no host pointer is
+ *     retained; host outputs are complete when the call returns [render() is synchronous, render.rs:61];
+ *   - a context is single-threaded-use; distinct contexts are independent;
+ *   - pixel layout is the reference's: row-major, y = 0 is the top row, RGBA8 with A = 255
+ *     (render.rs:22-29,110);
+ *   - random numbers: the reference uses an OS-seeded thread_rng() and is not reproducible; here every
+ *     (seed, pixel index, sample index) owns a counter-based stream, so a frame is a pure function of
+ *     (scene, camera, settings, size, seed) for any number of GPUs.
+ *
+ * There is no CPU fallback: every compute entry point fails with RTR_ERR_NO_DEVICE when no gfx950
+ * device is usable.
+ */
+#ifndef RTR_HIP_H
+#define RTR_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RTR_ABI_VERSION 1
+
+typedef enum rtr_status {
+    RTR_OK = 0,
+    RTR_ERR_INVALID_ARGUMENT = -1,
+    RTR_ERR_NO_DEVICE = -2,        /* no HIP device / context created host-only */
+    RTR_ERR_HIP = -3,              /* a HIP runtime call failed; see rtr_last_error */
+    RTR_ERR_BAD_INDEX = -4,        /* material / vertex / object index out of bounds (scene.rs:106-110 panics) */
+    RTR_ERR_NAN_CENTROID = -5,     /* partial_cmp().unwrap() in the BVH builder would panic (bvh.rs:99,109,119) */
+    RTR_ERR_BAD_SETTINGS = -6,     /* clamp_indirect NaN/negative (f32::clamp panics, render.rs:95), empty target */
+    RTR_ERR_NO_SCENE = -7,         /* render before rtr_upload_scene */
+    RTR_ERR_UNSUPPORTED = -8,      /* scene feature outside the GPU path (Volume objects: SURVEY section 8f N3) */
+    RTR_ERR_OUT_OF_MEMORY = -9
+} rtr_status;
+
+/* lib/materials.rs, lib/volume.rs:75-88 */
+typedef enum rtr_material_kind {
+    RTR_MAT_LAMBERTIAN = 0, /* rgb = albedo                     materials.rs:18-42  */
+    RTR_MAT_METAL = 1,      /* rgb = albedo, param = fuzz       materials.rs:44-71  */
+    RTR_MAT_EMISSION = 2,   /* rgb = color*strength             materials.rs:73-91  */
+    RTR_MAT_DIELECTRIC = 3, /* param = ir                       materials.rs:93-139 */
+    RTR_MAT_MIX = 4,        /* param = factor, first/second = indices into the same materials array, both
+                               greater than the mix's own index (nested boxes flattened)  materials.rs:141-157 */
+    RTR_MAT_ISOTROPIC = 5   /* rgb = color                      volume.rs:75-88 */
+} rtr_material_kind;
+
+typedef enum rtr_object_kind { RTR_OBJ_SPHERE = 0, RTR_OBJ_MESH = 1 } rtr_object_kind;
+typedef enum rtr_background_kind { RTR_BG_UNIFORM = 0, RTR_BG_GRADIENT = 1, RTR_BG_SKYMAP = 2 } rtr_background_kind;
+/* RenderMode, lib/core/scene.rs:14-20 */
+typedef enum rtr_render_mode { RTR_MODE_FULL = 0, RTR_MODE_CLAY = 1, RTR_MODE_RANDOM = 2, RTR_MODE_NORMAL = 3 } rtr_render_mode;
+
+/* Sphere, lib/objects.rs:15-20 */
+typedef struct rtr_sphere {
+    float center[3];
+    float radius;
+    uint32_t material;
+} rtr_sphere;
+
+/* Mesh::from_buffers inputs, lib/core/mesh.rs:78-82: (position, normal) vertex buffer + u32 triangle list */
+typedef struct rtr_mesh {
+    const float *positions; /* n_verts * 3 */
+    const float *normals;   /* n_verts * 3 */
+    const uint32_t *indices; /* n_tris * 3 */
+    uint32_t n_verts;
+    uint32_t n_tris;
+    uint32_t material;
+    uint32_t reserved;
+} rtr_mesh;
+
+typedef struct rtr_material {
+    uint32_t kind; /* rtr_material_kind */
+    float rgb[3];
+    float param;
+    uint32_t first;
+    uint32_t second;
+} rtr_material;
+
+/* Scene.objects is heterogeneous and ordered (scene.rs:37); order decides BVH ties and the linear scan */
+typedef struct rtr_object {
+    uint32_t kind;  /* rtr_object_kind */
+    uint32_t index; /* into spheres[] or meshes[] */
+} rtr_object;
+
+/* lib/backgrounds.rs */
+typedef struct rtr_background {
+    uint32_t kind;      /* rtr_background_kind */
+    float a[3];         /* uniform colour | gradient top */
+    float b[3];         /* gradient bottom */
+    const float *image; /* skymap: width*height RGB float triples, row 0 = top scanline (backgrounds.rs:68) */
+    uint32_t width;
+    uint32_t height;
+} rtr_background;
+
+typedef struct rtr_scene_desc {
+    const rtr_object *objects;
+    uint32_t n_objects;
+    const rtr_sphere *spheres;
+    uint32_t n_spheres;
+    const rtr_mesh *meshes;
+    uint32_t n_meshes;
+    const rtr_material *materials;
+    uint32_t n_materials;
+    rtr_background background;
+} rtr_scene_desc;
+
+/* Camera, lib/core/camera.rs:27-34 */
+typedef struct rtr_camera {
+    float lookfrom[3];
+    float lookat[3];
+    float vertical[3];
+    float vertical_fov; /* degrees */
+    float aspect_ratio; /* NOT derived from the target size (camera.rs:41) */
+} rtr_camera;
+
+/* RenderSettings, lib/core/scene.rs:22-30 (field for field) */
+typedef struct rtr_settings {
+    uint32_t samples_per_pixel;
+    uint32_t max_ray_depth;         /* u8 in the reference: values above 255 are rejected */
+    float clamp_indirect;
+    uint32_t enable_multithreading; /* accepted for parity; the GPU path is always parallel */
+    uint32_t enable_bvh_tree;
+    uint32_t mode;                  /* rtr_render_mode */
+} rtr_settings;
+
+typedef struct rtr_scene_info {
+    uint32_t n_objects, n_spheres, n_meshes, n_triangles, n_materials;
+    uint32_t n_leaves;      /* leaves of the flattened two-level tree (spheres + triangles) */
+    uint32_t n_nodes;       /* inner (Split) nodes */
+    uint32_t tree_height;   /* longest root-to-leaf path in Split nodes: the traversal stack bound */
+    uint32_t spheres_only;  /* 1 when every object is a sphere */
+    uint64_t device_bytes;  /* HBM resident bytes for this scene */
+} rtr_scene_info;
+
+typedef struct rtr_stats {
+    uint64_t primary_samples; /* W*H*spp of the last render (this shard's share) */
+    uint64_t segments;        /* ray segments = world.hit calls (render.rs:38) counted on the device */
+    double kernel_ms;         /* HIP-event time of the last render kernel on its stream */
+    double resolve_ms;        /* HIP-event time of the last resolve kernel (0 when fused) */
+    double upload_ms;         /* host build + flatten + copy of the last rtr_upload_scene (wall) */
+    uint32_t launches;        /* render kernels launched by this context so far */
+    uint32_t vgprs, lds_bytes, block_threads; /* launch configuration of the last render kernel */
+} rtr_stats;
+
+typedef struct rtr_context rtr_context;
+
+/* device >= 0: bind that HIP device.  device == -1: host-only context (scene lowering, BVH build and the
+ * introspection calls work; every compute call returns RTR_ERR_NO_DEVICE). */
+int rtr_create(int device, rtr_context **out);
+void rtr_destroy(rtr_context *ctx);
+/* message for the last failing call on ctx (ctx == NULL: last failing rtr_create on this thread) */
+const char *rtr_last_error(const rtr_context *ctx);
+int rtr_abi_version(void);
+
+/* Lower + build + flatten + copy to HBM.  Replaces any previous scene of the context. */
+int rtr_upload_scene(rtr_context *ctx, const rtr_scene_desc *scene);
+int rtr_scene_info_get(const rtr_context *ctx, rtr_scene_info *out);
+/* Leaves of the flattened tree in the reference's depth-first order (left before right, bvh.rs:162-163).
+ * out[i] = (object index << 32) | triangle handle (0 for spheres).  Returns the leaf count (<= cap used). */
+int64_t rtr_bvh_leaf_order(const rtr_context *ctx, uint64_t *out, uint64_t cap);
+
+/* render(): the whole frame, host outputs.  rgba8: width*height*4 bytes or NULL.  mean_rgb: width*height*3
+ * floats, colour/spp BEFORE the sqrt gamma (render.rs:103-107), or NULL. */
+int rtr_render(rtr_context *ctx, const rtr_camera *camera, const rtr_settings *settings, uint32_t width,
+               uint32_t height, uint64_t seed, uint8_t *rgba8, float *mean_rgb);
+int rtr_render_rgba8(rtr_context *ctx, const rtr_camera *camera, const rtr_settings *settings, uint32_t width,
+                     uint32_t height, uint64_t seed, uint8_t *rgba8);
+int rtr_render_f32(rtr_context *ctx, const rtr_camera *camera, const rtr_settings *settings, uint32_t width,
+                   uint32_t height, uint64_t seed, float *mean_rgb);
+
+/* --- device-resident entry points (multi-GPU sharding, benchmarking); all asynchronous on `stream`
+ *     (a hipStream_t; NULL = the context's own stream) --------------------------------------------- */
+
+/* Fused single-GPU frame: integrate + clamp + mean + sqrt + RGBA8, output in HBM.
+ * d_rgba8: device pointer, width*height*4 bytes. */
+int rtr_render_frame_device(rtr_context *ctx, const rtr_camera *camera, const rtr_settings *settings, uint32_t width,
+                            uint32_t height, uint64_t seed, uint8_t *d_rgba8, void *stream);
+/* Sharded integrate: 8x8-pixel tiles t with t % n_shards == shard are rendered; for each of their pixels the
+ * sum over samples of the clamped radiance (render.rs:95-99) is STORED to d_sum_rgba[pixel*4 .. +3] (w = 0).
+ * Pixels of other shards are not touched: zero the buffer first, then a sum over shards (RCCL reduce) is the
+ * full frame, bit-identical to the single-GPU sum because x + 0 = x. */
+int rtr_render_tiles_device(rtr_context *ctx, const rtr_camera *camera, const rtr_settings *settings, uint32_t width,
+                            uint32_t height, uint64_t seed, uint32_t shard, uint32_t n_shards, float *d_sum_rgba,
+                            void *stream);
+/* mean = sum/spp, sqrt gamma, RGBA8 (render.rs:103-110).  d_rgba8 and/or d_mean_rgb may be NULL. */
+int rtr_resolve_device(rtr_context *ctx, const float *d_sum_rgba, uint32_t samples_per_pixel, uint32_t width,
+                       uint32_t height, uint8_t *d_rgba8, float *d_mean_rgb, void *stream);
+
+/* Waits for the context's outstanding work, then reports counters and HIP-event timings. */
+int rtr_get_stats(rtr_context *ctx, rtr_stats *out);
+/* HIP-event durations (ms) of the most recent render kernels, oldest first; returns how many were written
+ * (at most cap, at most 64).  Waits for outstanding work. */
+int rtr_kernel_times_ms(rtr_context *ctx, float *out, uint32_t cap);
+/* Device-counted ray segments of the same launches, in the same order. */
+int rtr_segment_counts(rtr_context *ctx, uint64_t *out, uint32_t cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RTR_HIP_H */

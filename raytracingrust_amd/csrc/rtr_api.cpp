@@ -1,0 +1,439 @@
+// rtr_api.cpp -- implementation of the C ABI declared in include/rtr_hip.h (host side, HIP runtime).
+//
+// A context owns one HIP device, one stream, the scene's HBM buffers, a ring of HIP events around the
+// render kernels and a ring of device-side segment counters.  There is no CPU rendering path in this
+// library: without a device every compute entry point returns RTR_ERR_NO_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/rtr_hip.h"
+#include "rtr_device.h"
+#include "rtr_scene.h"
+
+namespace rtr {
+hipError_t launch_render(const RenderParams &p, uint32_t grid, uint32_t lds_bytes, hipStream_t stream);
+hipError_t launch_resolve(const float *sum_rgba, uint32_t spp, uint32_t n_pixels, uint8_t *rgba8, float *mean_rgb,
+                          hipStream_t stream);
+hipError_t render_kernel_attributes(uint32_t world, int *vgprs, int *static_lds);
+} // namespace rtr
+
+namespace {
+constexpr int kRing = 64;
+thread_local std::string g_create_error;
+} // namespace
+
+struct rtr_context {
+    int device = -1; // -1: host-only
+    hipStream_t stream = nullptr;
+    std::string error;
+    // scene
+    bool have_scene = false;
+    rtr::FlatScene flat; // host copy (kept for introspection)
+    void *d_nodes = nullptr, *d_leaf_hot = nullptr, *d_leaf_cold = nullptr, *d_lin = nullptr, *d_objects = nullptr,
+         *d_materials = nullptr, *d_sky = nullptr;
+    uint64_t device_bytes = 0;
+    double upload_ms = 0.0;
+    // per-launch bookkeeping
+    hipEvent_t ev_start[kRing] = {}, ev_stop[kRing] = {};
+    hipEvent_t ev_res_start = nullptr, ev_res_stop = nullptr;
+    bool resolve_timed = false;
+    unsigned long long *d_counters = nullptr; // kRing slots
+    uint32_t *d_error_flag = nullptr;
+    uint32_t launches = 0;
+    uint64_t last_primary = 0;
+    uint32_t last_lds = 0, last_vgprs = 0;
+    // scratch for the host-output render
+    void *d_rgba8 = nullptr; size_t rgba8_cap = 0;
+    void *d_mean = nullptr; size_t mean_cap = 0;
+};
+
+namespace {
+
+int fail(rtr_context *ctx, int code, const std::string &msg) {
+    if (ctx) ctx->error = msg;
+    return code;
+}
+int fail_hip(rtr_context *ctx, hipError_t e, const char *what) {
+    return fail(ctx, RTR_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+#define RTR_HIP_TRY(ctx, call)                                   \
+    do {                                                         \
+        hipError_t e_ = (call);                                  \
+        if (e_ != hipSuccess) return fail_hip(ctx, e_, #call);   \
+    } while (0)
+
+void free_scene(rtr_context *ctx) {
+    void **bufs[] = {&ctx->d_nodes, &ctx->d_leaf_hot, &ctx->d_leaf_cold, &ctx->d_lin, &ctx->d_objects, &ctx->d_materials, &ctx->d_sky};
+    for (void **b : bufs) {
+        if (*b) (void)hipFree(*b);
+        *b = nullptr;
+    }
+    ctx->device_bytes = 0;
+    ctx->have_scene = false;
+}
+
+template <typename T>
+int upload_vec(rtr_context *ctx, const std::vector<T> &v, void **dst) {
+    *dst = nullptr;
+    if (v.empty()) return RTR_OK;
+    size_t bytes = v.size() * sizeof(T);
+    RTR_HIP_TRY(ctx, hipMalloc(dst, bytes));
+    RTR_HIP_TRY(ctx, hipMemcpy(*dst, v.data(), bytes, hipMemcpyHostToDevice));
+    ctx->device_bytes += bytes;
+    return RTR_OK;
+}
+
+int check_settings(rtr_context *ctx, const rtr_camera *camera, const rtr_settings *st, uint32_t width, uint32_t height) {
+    if (!camera || !st) return fail(ctx, RTR_ERR_INVALID_ARGUMENT, "null camera or settings");
+    if (width == 0 || height == 0) return fail(ctx, RTR_ERR_BAD_SETTINGS, "empty render target");
+    if ((uint64_t)width * height > 0x7FFFFFFFull) return fail(ctx, RTR_ERR_BAD_SETTINGS, "render target too large");
+    if (st->max_ray_depth > 255u) return fail(ctx, RTR_ERR_BAD_SETTINGS, "max_ray_depth is a u8 in the reference (scene.rs:25)");
+    if (!(st->clamp_indirect == st->clamp_indirect) || st->clamp_indirect < 0.0f)
+        return fail(ctx, RTR_ERR_BAD_SETTINGS, "clamp_indirect NaN or negative: f32::clamp panics (render.rs:95)");
+    if (st->mode > RTR_MODE_NORMAL) return fail(ctx, RTR_ERR_BAD_SETTINGS, "unknown render mode");
+    return RTR_OK;
+}
+
+// Fill the launch parameters and launch the integrator.  Exactly one of (sum_rgba) / (rgba8|mean_rgb) is used.
+int launch_frame(rtr_context *ctx, const rtr_camera *camera, const rtr_settings *st, uint32_t width, uint32_t height,
+                 uint64_t seed, uint32_t shard, uint32_t n_shards, float *d_sum_rgba, uint8_t *d_rgba8, float *d_mean_rgb,
+                 hipStream_t stream) {
+    if (!ctx) return RTR_ERR_INVALID_ARGUMENT;
+    if (ctx->device < 0) return fail(ctx, RTR_ERR_NO_DEVICE, "host-only context: no HIP device bound (there is no CPU fallback)");
+    if (!ctx->have_scene) return fail(ctx, RTR_ERR_NO_SCENE, "rtr_upload_scene has not been called");
+    int rc = check_settings(ctx, camera, st, width, height);
+    if (rc) return rc;
+    if (n_shards == 0 || shard >= n_shards) return fail(ctx, RTR_ERR_INVALID_ARGUMENT, "shard must be < n_shards");
+    RTR_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (!stream) stream = ctx->stream;
+
+    const rtr::FlatScene &fs = ctx->flat;
+    rtr::RenderParams p;
+    std::memset(&p, 0, sizeof p);
+    rtr::camera_ray_origin(*camera, p.cam_origin, p.cam_horizontal, p.cam_vertical, p.cam_llc);
+    p.width_m1 = (float)(width - 1u);   // (target.width - 1) as Float, render.rs:88
+    p.height_m1 = (float)(height - 1u); // render.rs:89
+    p.width = width; p.height = height;
+    p.spp = st->samples_per_pixel; p.max_depth = st->max_ray_depth; p.mode = st->mode;
+    p.clamp_indirect = st->clamp_indirect;
+    p.seed_lo = (uint32_t)seed; p.seed_hi = (uint32_t)(seed >> 32);
+    // render.rs:68-72: the tree when enable_bvh_tree, else the linear scan of scene.rs:141-157
+    if (st->enable_bvh_tree) { p.world = rtr::WORLD_BVH; p.stack_cap = fs.tree_height + 1u; }
+    else if (fs.spheres_only) { p.world = rtr::WORLD_LINEAR_SPHERES; p.stack_cap = 0u; }
+    else { p.world = rtr::WORLD_LINEAR_GENERIC; p.stack_cap = fs.mesh_height + 1u; }
+    p.n_objects = fs.n_objects;
+    p.root_ref = fs.root_ref;
+    std::memcpy(p.root_box, fs.root_box, sizeof p.root_box);
+    p.nodes = static_cast<const rtr::DevNode *>(ctx->d_nodes);
+    p.leaf_hot = static_cast<const rtr::DevLeafHot *>(ctx->d_leaf_hot);
+    p.leaf_cold = static_cast<const rtr::DevLeafCold *>(ctx->d_leaf_cold);
+    p.lin_spheres = static_cast<const rtr::DevLinSphere *>(ctx->d_lin);
+    p.objects = static_cast<const rtr::DevObject *>(ctx->d_objects);
+    p.materials = static_cast<const rtr::DevMaterial *>(ctx->d_materials);
+    p.n_materials = (uint32_t)fs.materials.size();
+    p.bg_kind = fs.bg_kind;
+    std::memcpy(p.bg_a, fs.bg_a, sizeof p.bg_a);
+    std::memcpy(p.bg_b, fs.bg_b, sizeof p.bg_b);
+    p.sky = static_cast<const float *>(ctx->d_sky);
+    p.sky_w = fs.sky_w; p.sky_h = fs.sky_h;
+    p.tiles_x = (width + 7u) / 8u;
+    uint32_t tiles_y = (height + 7u) / 8u;
+    p.tiles_total = p.tiles_x * tiles_y;
+    p.shard = shard; p.n_shards = n_shards;
+    p.sum_rgba = d_sum_rgba; p.rgba8 = d_rgba8; p.mean_rgb = d_mean_rgb;
+    const uint32_t slot = ctx->launches % kRing;
+    p.counter = ctx->d_counters + slot;
+    p.error_flag = ctx->d_error_flag;
+
+    uint32_t grid = p.tiles_total > shard ? (p.tiles_total - shard + n_shards - 1u) / n_shards : 0u;
+    // dynamic LDS per wave: attenuation chain + traversal stack (refs + entry distances)
+    uint32_t lds_bytes = (p.max_depth + 2u * p.stack_cap) * 64u * 4u;
+    if (lds_bytes > 160u * 1024u) return fail(ctx, RTR_ERR_UNSUPPORTED, "max_ray_depth + tree height exceed one CU's LDS");
+    ctx->last_lds = lds_bytes;
+    ctx->last_primary = 0;
+    // this shard's share of W*H*spp
+    {
+        uint64_t pixels = 0;
+        for (uint32_t t = shard; t < p.tiles_total; t += n_shards) {
+            uint32_t tx = t % p.tiles_x, ty = t / p.tiles_x;
+            uint32_t w = (tx * 8u + 8u <= width) ? 8u : width - tx * 8u;
+            uint32_t h = (ty * 8u + 8u <= height) ? 8u : height - ty * 8u;
+            pixels += (uint64_t)w * h;
+        }
+        ctx->last_primary = pixels * st->samples_per_pixel;
+    }
+    RTR_HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters + slot, 0, sizeof(unsigned long long), stream));
+    RTR_HIP_TRY(ctx, hipEventRecord(ctx->ev_start[slot], stream));
+    if (grid > 0) RTR_HIP_TRY(ctx, rtr::launch_render(p, grid, lds_bytes, stream));
+    RTR_HIP_TRY(ctx, hipEventRecord(ctx->ev_stop[slot], stream));
+    ctx->launches++;
+    {
+        int vg = 0, sl = 0;
+        if (rtr::render_kernel_attributes(p.world, &vg, &sl) == hipSuccess) ctx->last_vgprs = (uint32_t)vg;
+    }
+    return RTR_OK;
+}
+
+int ensure_scratch(rtr_context *ctx, void **buf, size_t *cap, size_t need) {
+    if (*cap >= need) return RTR_OK;
+    if (*buf) (void)hipFree(*buf);
+    *buf = nullptr; *cap = 0;
+    RTR_HIP_TRY(ctx, hipMalloc(buf, need));
+    *cap = need;
+    return RTR_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int rtr_abi_version(void) { return RTR_ABI_VERSION; }
+
+int rtr_create(int device, rtr_context **out) {
+    if (!out) { g_create_error = "null out pointer"; return RTR_ERR_INVALID_ARGUMENT; }
+    *out = nullptr;
+    rtr_context *ctx = new (std::nothrow) rtr_context();
+    if (!ctx) { g_create_error = "out of memory"; return RTR_ERR_OUT_OF_MEMORY; }
+    if (device < 0) { // host-only
+        ctx->device = -1;
+        *out = ctx;
+        return RTR_OK;
+    }
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0 || device >= count) {
+        g_create_error = std::string("no usable HIP device ") + std::to_string(device) + " (" +
+                         (e != hipSuccess ? hipGetErrorString(e) : "device count too small") + "); there is no CPU fallback";
+        delete ctx;
+        return RTR_ERR_NO_DEVICE;
+    }
+    auto bail = [&](hipError_t err, const char *what) {
+        g_create_error = std::string(what) + ": " + hipGetErrorString(err);
+        rtr_destroy(ctx);
+        return (int)RTR_ERR_HIP;
+    };
+    ctx->device = device;
+    if ((e = hipSetDevice(device)) != hipSuccess) { ctx->device = -1; return bail(e, "hipSetDevice"); }
+    if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
+    for (int i = 0; i < kRing; i++) {
+        if ((e = hipEventCreate(&ctx->ev_start[i])) != hipSuccess) return bail(e, "hipEventCreate");
+        if ((e = hipEventCreate(&ctx->ev_stop[i])) != hipSuccess) return bail(e, "hipEventCreate");
+    }
+    if ((e = hipEventCreate(&ctx->ev_res_start)) != hipSuccess) return bail(e, "hipEventCreate");
+    if ((e = hipEventCreate(&ctx->ev_res_stop)) != hipSuccess) return bail(e, "hipEventCreate");
+    if ((e = hipMalloc((void **)&ctx->d_counters, kRing * sizeof(unsigned long long))) != hipSuccess) return bail(e, "hipMalloc");
+    if ((e = hipMemset(ctx->d_counters, 0, kRing * sizeof(unsigned long long))) != hipSuccess) return bail(e, "hipMemset");
+    if ((e = hipMalloc((void **)&ctx->d_error_flag, sizeof(uint32_t))) != hipSuccess) return bail(e, "hipMalloc");
+    if ((e = hipMemset(ctx->d_error_flag, 0, sizeof(uint32_t))) != hipSuccess) return bail(e, "hipMemset");
+    *out = ctx;
+    return RTR_OK;
+}
+
+void rtr_destroy(rtr_context *ctx) {
+    if (!ctx) return;
+    if (ctx->device >= 0) {
+        (void)hipSetDevice(ctx->device);
+        if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+        free_scene(ctx);
+        for (int i = 0; i < kRing; i++) {
+            if (ctx->ev_start[i]) (void)hipEventDestroy(ctx->ev_start[i]);
+            if (ctx->ev_stop[i]) (void)hipEventDestroy(ctx->ev_stop[i]);
+        }
+        if (ctx->ev_res_start) (void)hipEventDestroy(ctx->ev_res_start);
+        if (ctx->ev_res_stop) (void)hipEventDestroy(ctx->ev_res_stop);
+        if (ctx->d_counters) (void)hipFree(ctx->d_counters);
+        if (ctx->d_error_flag) (void)hipFree(ctx->d_error_flag);
+        if (ctx->d_rgba8) (void)hipFree(ctx->d_rgba8);
+        if (ctx->d_mean) (void)hipFree(ctx->d_mean);
+        if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    }
+    delete ctx;
+}
+
+const char *rtr_last_error(const rtr_context *ctx) { return ctx ? ctx->error.c_str() : g_create_error.c_str(); }
+
+int rtr_upload_scene(rtr_context *ctx, const rtr_scene_desc *scene) {
+    if (!ctx) return RTR_ERR_INVALID_ARGUMENT;
+    if (!scene) return fail(ctx, RTR_ERR_INVALID_ARGUMENT, "null scene");
+    auto t0 = std::chrono::steady_clock::now();
+    rtr::FlatScene flat;
+    std::string err;
+    int rc = rtr::build_flat_scene(*scene, flat, err);
+    if (rc != RTR_OK) return fail(ctx, rc, err);
+    if (ctx->device >= 0) {
+        RTR_HIP_TRY(ctx, hipSetDevice(ctx->device));
+        RTR_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        free_scene(ctx);
+        if ((rc = upload_vec(ctx, flat.nodes, &ctx->d_nodes))) return rc;
+        if ((rc = upload_vec(ctx, flat.leaf_hot, &ctx->d_leaf_hot))) return rc;
+        if ((rc = upload_vec(ctx, flat.leaf_cold, &ctx->d_leaf_cold))) return rc;
+        if ((rc = upload_vec(ctx, flat.lin_spheres, &ctx->d_lin))) return rc;
+        if ((rc = upload_vec(ctx, flat.objects, &ctx->d_objects))) return rc;
+        if ((rc = upload_vec(ctx, flat.materials, &ctx->d_materials))) return rc;
+        if ((rc = upload_vec(ctx, flat.sky, &ctx->d_sky))) return rc;
+    }
+    flat.sky.clear(); // the texels live in HBM only
+    flat.sky.shrink_to_fit();
+    ctx->flat = std::move(flat);
+    ctx->have_scene = true;
+    ctx->upload_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return RTR_OK;
+}
+
+int rtr_scene_info_get(const rtr_context *ctx, rtr_scene_info *out) {
+    if (!ctx || !out) return RTR_ERR_INVALID_ARGUMENT;
+    if (!ctx->have_scene) return RTR_ERR_NO_SCENE;
+    const rtr::FlatScene &fs = ctx->flat;
+    std::memset(out, 0, sizeof *out);
+    out->n_objects = fs.n_objects; out->n_spheres = fs.n_spheres; out->n_meshes = fs.n_meshes;
+    out->n_triangles = fs.n_triangles; out->n_materials = (uint32_t)fs.materials.size();
+    out->n_leaves = (uint32_t)fs.leaf_hot.size(); out->n_nodes = (uint32_t)fs.nodes.size();
+    out->tree_height = fs.tree_height; out->spheres_only = fs.spheres_only ? 1u : 0u;
+    out->device_bytes = ctx->device_bytes;
+    return RTR_OK;
+}
+
+int64_t rtr_bvh_leaf_order(const rtr_context *ctx, uint64_t *out, uint64_t cap) {
+    if (!ctx) return RTR_ERR_INVALID_ARGUMENT;
+    if (!ctx->have_scene) return RTR_ERR_NO_SCENE;
+    const auto &cold = ctx->flat.leaf_cold;
+    if (out)
+        for (uint64_t i = 0; i < cold.size() && i < cap; i++) out[i] = ((uint64_t)cold[i].object << 32) | cold[i].handle;
+    return (int64_t)cold.size();
+}
+
+int rtr_render_frame_device(rtr_context *ctx, const rtr_camera *camera, const rtr_settings *settings, uint32_t width,
+                            uint32_t height, uint64_t seed, uint8_t *d_rgba8, void *stream) {
+    if (!ctx) return RTR_ERR_INVALID_ARGUMENT;
+    if (!d_rgba8) return fail(ctx, RTR_ERR_INVALID_ARGUMENT, "null output");
+    return launch_frame(ctx, camera, settings, width, height, seed, 0u, 1u, nullptr, d_rgba8, nullptr, (hipStream_t)stream);
+}
+
+int rtr_render_tiles_device(rtr_context *ctx, const rtr_camera *camera, const rtr_settings *settings, uint32_t width,
+                            uint32_t height, uint64_t seed, uint32_t shard, uint32_t n_shards, float *d_sum_rgba,
+                            void *stream) {
+    if (!ctx) return RTR_ERR_INVALID_ARGUMENT;
+    if (!d_sum_rgba) return fail(ctx, RTR_ERR_INVALID_ARGUMENT, "null output");
+    return launch_frame(ctx, camera, settings, width, height, seed, shard, n_shards, d_sum_rgba, nullptr, nullptr, (hipStream_t)stream);
+}
+
+int rtr_resolve_device(rtr_context *ctx, const float *d_sum_rgba, uint32_t samples_per_pixel, uint32_t width,
+                       uint32_t height, uint8_t *d_rgba8, float *d_mean_rgb, void *stream) {
+    if (!ctx) return RTR_ERR_INVALID_ARGUMENT;
+    if (ctx->device < 0) return fail(ctx, RTR_ERR_NO_DEVICE, "host-only context: no HIP device bound (there is no CPU fallback)");
+    if (!d_sum_rgba || width == 0 || height == 0) return fail(ctx, RTR_ERR_INVALID_ARGUMENT, "bad resolve arguments");
+    RTR_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    RTR_HIP_TRY(ctx, hipEventRecord(ctx->ev_res_start, s));
+    RTR_HIP_TRY(ctx, rtr::launch_resolve(d_sum_rgba, samples_per_pixel, width * height, d_rgba8, d_mean_rgb, s));
+    RTR_HIP_TRY(ctx, hipEventRecord(ctx->ev_res_stop, s));
+    ctx->resolve_timed = true;
+    return RTR_OK;
+}
+
+int rtr_render(rtr_context *ctx, const rtr_camera *camera, const rtr_settings *settings, uint32_t width, uint32_t height,
+               uint64_t seed, uint8_t *rgba8, float *mean_rgb) {
+    if (!ctx) return RTR_ERR_INVALID_ARGUMENT;
+    if (!rgba8 && !mean_rgb) return fail(ctx, RTR_ERR_INVALID_ARGUMENT, "no output requested");
+    if (ctx->device < 0) return fail(ctx, RTR_ERR_NO_DEVICE, "host-only context: no HIP device bound (there is no CPU fallback)");
+    int rc = check_settings(ctx, camera, settings, width, height);
+    if (rc) return rc;
+    RTR_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    size_t npx = (size_t)width * height;
+    uint8_t *d8 = nullptr;
+    float *dm = nullptr;
+    if (rgba8) {
+        if ((rc = ensure_scratch(ctx, &ctx->d_rgba8, &ctx->rgba8_cap, npx * 4))) return rc;
+        d8 = static_cast<uint8_t *>(ctx->d_rgba8);
+    }
+    if (mean_rgb) {
+        if ((rc = ensure_scratch(ctx, &ctx->d_mean, &ctx->mean_cap, npx * 3 * sizeof(float)))) return rc;
+        dm = static_cast<float *>(ctx->d_mean);
+    }
+    rc = launch_frame(ctx, camera, settings, width, height, seed, 0u, 1u, nullptr, d8, dm, ctx->stream);
+    if (rc) return rc;
+    if (rgba8) RTR_HIP_TRY(ctx, hipMemcpyAsync(rgba8, d8, npx * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (mean_rgb) RTR_HIP_TRY(ctx, hipMemcpyAsync(mean_rgb, dm, npx * 3 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    RTR_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    uint32_t flag = 0;
+    RTR_HIP_TRY(ctx, hipMemcpy(&flag, ctx->d_error_flag, sizeof flag, hipMemcpyDeviceToHost));
+    if (flag) return fail(ctx, RTR_ERR_HIP, "traversal stack overflow on the device (internal error)");
+    return RTR_OK;
+}
+
+int rtr_render_rgba8(rtr_context *ctx, const rtr_camera *camera, const rtr_settings *settings, uint32_t width,
+                     uint32_t height, uint64_t seed, uint8_t *rgba8) {
+    if (!ctx) return RTR_ERR_INVALID_ARGUMENT;
+    if (!rgba8) return fail(ctx, RTR_ERR_INVALID_ARGUMENT, "null output");
+    return rtr_render(ctx, camera, settings, width, height, seed, rgba8, nullptr);
+}
+
+int rtr_render_f32(rtr_context *ctx, const rtr_camera *camera, const rtr_settings *settings, uint32_t width,
+                   uint32_t height, uint64_t seed, float *mean_rgb) {
+    if (!ctx) return RTR_ERR_INVALID_ARGUMENT;
+    if (!mean_rgb) return fail(ctx, RTR_ERR_INVALID_ARGUMENT, "null output");
+    return rtr_render(ctx, camera, settings, width, height, seed, nullptr, mean_rgb);
+}
+
+int rtr_get_stats(rtr_context *ctx, rtr_stats *out) {
+    if (!ctx || !out) return RTR_ERR_INVALID_ARGUMENT;
+    std::memset(out, 0, sizeof *out);
+    out->upload_ms = ctx->upload_ms;
+    out->launches = ctx->launches;
+    out->primary_samples = ctx->last_primary;
+    out->lds_bytes = ctx->last_lds;
+    out->vgprs = ctx->last_vgprs;
+    out->block_threads = 64;
+    if (ctx->device < 0 || ctx->launches == 0) return RTR_OK;
+    RTR_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    RTR_HIP_TRY(ctx, hipDeviceSynchronize());
+    uint32_t slot = (ctx->launches - 1u) % kRing;
+    float ms = 0.0f;
+    RTR_HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev_start[slot], ctx->ev_stop[slot]));
+    out->kernel_ms = ms;
+    if (ctx->resolve_timed) {
+        RTR_HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev_res_start, ctx->ev_res_stop));
+        out->resolve_ms = ms;
+    }
+    unsigned long long seg = 0;
+    RTR_HIP_TRY(ctx, hipMemcpy(&seg, ctx->d_counters + slot, sizeof seg, hipMemcpyDeviceToHost));
+    out->segments = seg;
+    return RTR_OK;
+}
+
+int rtr_kernel_times_ms(rtr_context *ctx, float *out, uint32_t cap) {
+    if (!ctx || !out) return RTR_ERR_INVALID_ARGUMENT;
+    if (ctx->device < 0 || ctx->launches == 0) return 0;
+    RTR_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    RTR_HIP_TRY(ctx, hipDeviceSynchronize());
+    uint32_t n = ctx->launches < (uint32_t)kRing ? ctx->launches : (uint32_t)kRing;
+    if (n > cap) n = cap;
+    for (uint32_t i = 0; i < n; i++) {
+        uint32_t slot = (ctx->launches - n + i) % kRing;
+        float ms = 0.0f;
+        RTR_HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev_start[slot], ctx->ev_stop[slot]));
+        out[i] = ms;
+    }
+    return (int)n;
+}
+
+int rtr_segment_counts(rtr_context *ctx, uint64_t *out, uint32_t cap) {
+    if (!ctx || !out) return RTR_ERR_INVALID_ARGUMENT;
+    if (ctx->device < 0 || ctx->launches == 0) return 0;
+    RTR_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    RTR_HIP_TRY(ctx, hipDeviceSynchronize());
+    uint32_t n = ctx->launches < (uint32_t)kRing ? ctx->launches : (uint32_t)kRing;
+    if (n > cap) n = cap;
+    unsigned long long ring[kRing];
+    RTR_HIP_TRY(ctx, hipMemcpy(ring, ctx->d_counters, sizeof ring, hipMemcpyDeviceToHost));
+    for (uint32_t i = 0; i < n; i++) out[i] = ring[(ctx->launches - n + i) % kRing];
+    return (int)n;
+}
+
+} // extern "C"

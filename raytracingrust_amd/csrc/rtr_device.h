@@ -1,0 +1,111 @@
+// rtr_device.h -- plain-old-data shared by the host flattener and the gfx950 kernels.
+//
+// HBM layout of an uploaded scene (DESIGN.md "Data layout"):
+//   nodes[]      64 B per Split node of the reference's tree (lib/core/bvh.rs:52-56), preorder.  A node
+//                carries the boxes of its two CHILDREN, so one 64-B gather decides both descents; the
+//                box of the root lives in the launch parameters.  Leaves (bvh.rs `Object(u32)`) have no
+//                box in the reference and none here.
+//   leaf_hot[]   48 B per leaf, indexed by the leaf's rank L in the reference's depth-first order
+//                (left before right, bvh.rs:162-163).  Sphere: centre, radius, radius^2.
+//                Triangle: v0, e1 = v1-v0, e2 = v2-v0 (mesh.rs:160-161, hoisted: pure functions).
+//   leaf_cold[]  64 B per leaf, read once per segment for the winning leaf only: vertex normals,
+//                face normal (mesh.rs:86-90), material handle.
+//   lin_spheres[] 32 B per sphere in Scene.objects order: the linear world of scene.rs:141-157 when
+//                every object is a sphere (scenes/benchmark.json); read with wave-uniform indices.
+//   objects[]    32 B per object in Scene.objects order: root ref + root box, for the linear world
+//                with meshes.
+//   materials[]  32 B per material.
+//   sky[]        16 B per texel (RGB + pad) for SkyMap (backgrounds.rs:51-56).
+#pragma once
+#include <stdint.h>
+
+namespace rtr {
+
+constexpr uint32_t REF_NONE = 0xFFFFFFFFu;  // BvhNode::None
+constexpr uint32_t REF_LEAF = 0x80000000u;  // BvhNode::Object
+constexpr uint32_t REF_TRI = 0x40000000u;   // leaf is a triangle (else sphere)
+constexpr uint32_t REF_INDEX = 0x3FFFFFFFu; // leaf rank L, or node index
+
+struct alignas(16) DevNode {
+    float lmin[3], lmax[3];
+    float rmin[3], rmax[3];
+    uint32_t lref, rref;
+    uint32_t pad0, pad1;
+};
+static_assert(sizeof(DevNode) == 64, "node is one 64-byte gather");
+
+struct alignas(16) DevLeafHot {
+    float f[12];
+};
+static_assert(sizeof(DevLeafHot) == 48, "hot leaf record");
+
+struct alignas(16) DevLeafCold {
+    float n0[3]; uint32_t material;
+    float n1[3]; uint32_t object;
+    float n2[3]; uint32_t handle;
+    float fn[3]; uint32_t pad;
+};
+static_assert(sizeof(DevLeafCold) == 64, "cold leaf record");
+
+struct alignas(16) DevLinSphere {
+    float center[3]; float radius;
+    float radius2; uint32_t material; uint32_t pad0, pad1;
+};
+static_assert(sizeof(DevLinSphere) == 32, "linear-world sphere");
+
+struct alignas(16) DevObject {
+    uint32_t ref;
+    float box[6]; // root box when ref is a Split node
+    uint32_t pad;
+};
+static_assert(sizeof(DevObject) == 32, "object record");
+
+struct alignas(16) DevMaterial {
+    float rgb[3]; float param;
+    uint32_t kind, first, second, pad;
+};
+static_assert(sizeof(DevMaterial) == 32, "material record");
+
+enum WorldKind : uint32_t {
+    WORLD_LINEAR_SPHERES = 0, // scene.rs:141-157, every object a sphere
+    WORLD_BVH = 1,            // bvh.rs:43-50 over the two-level tree
+    WORLD_LINEAR_GENERIC = 2  // scene.rs:141-157 with meshes (each mesh traverses its own tree, mesh.rs:124-127)
+};
+
+// Launch parameters: one kernel argument block (scalar registers / kernarg segment).
+struct RenderParams {
+    // RayOrigin, camera.rs:11-17
+    float cam_origin[3], cam_horizontal[3], cam_vertical[3], cam_llc[3];
+    float width_m1, height_m1; // (W-1) as f32, (H-1) as f32  (render.rs:88-89)
+    uint32_t width, height;
+    uint32_t spp, max_depth, mode;
+    float clamp_indirect;
+    uint32_t seed_lo, seed_hi;
+    // world
+    uint32_t world, n_objects;
+    uint32_t root_ref;
+    float root_box[6];
+    uint32_t stack_cap; // entries per lane
+    const DevNode *nodes;
+    const DevLeafHot *leaf_hot;
+    const DevLeafCold *leaf_cold;
+    const DevLinSphere *lin_spheres;
+    const DevObject *objects;
+    const DevMaterial *materials;
+    uint32_t n_materials;
+    // background
+    uint32_t bg_kind;
+    float bg_a[3], bg_b[3];
+    const float *sky; // float4 texels
+    uint32_t sky_w, sky_h;
+    // tile sharding
+    uint32_t tiles_x, tiles_total, shard, n_shards;
+    // outputs
+    float *sum_rgba;             // float4 per pixel (sharded path) or nullptr
+    uint8_t *rgba8;              // fused path or nullptr
+    float *mean_rgb;             // fused path, optional
+    unsigned long long *counter; // segments
+    uint32_t *error_flag;        // set non-zero on traversal-stack overflow (never expected)
+};
+
+} // namespace rtr

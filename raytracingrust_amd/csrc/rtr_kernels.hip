@@ -1,0 +1,663 @@
+// rtr_kernels.hip -- the gfx950 path-tracing kernels (hand-written HIP for CDNA4, wave64).
+//
+// One lane = one pixel's path; one 64-lane wave = one 8x8 pixel tile (primary rays of a wave stay
+// coherent).  A lane whose path terminates immediately regenerates the next sample of its pixel inside
+// the same loop iteration ("lane regeneration"), so every trip of the wave's loop is one ray segment for
+// every live lane: path-length divergence never idles lanes, only the material switch and the rejection
+// sampler diverge.  Samples of a pixel are accumulated in registers in sample order, so the per-pixel sum
+// is the reference's sum (render.rs:84-100) bit for bit.
+//
+// Arithmetic contract: built with -ffp-contract=off and correctly rounded f32 divide/sqrt, every value
+// is computed by the reference's operation sequence (citations per function), so the float framebuffer
+// equals the CPU oracle's.  Hoisting is limited to pure functions of the same operands (1/d per ray,
+// |d|^2 per ray, r^2 per sphere, triangle edges).
+//
+// The attenuation product of a path is right-nested in the reference (render.rs:52:
+// att0*(att1*(...*terminal))); floats do not reassociate, so each bounce pushes the id of its
+// attenuation onto a per-lane chain in LDS and the product is replayed innermost-first on termination.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "rtr_device.h"
+
+namespace rtr {
+
+#define RTR_DEV __device__ __forceinline__
+
+struct V3 { float x, y, z; };
+RTR_DEV V3 mk(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
+RTR_DEV V3 ld3(const float *p) { return mk(p[0], p[1], p[2]); }
+RTR_DEV V3 add(V3 a, V3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+RTR_DEV V3 sub(V3 a, V3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+RTR_DEV V3 scale(V3 a, float s) { return mk(a.x * s, a.y * s, a.z * s); }
+RTR_DEV V3 divs(V3 a, float s) { return mk(a.x / s, a.y / s, a.z / s); }
+RTR_DEV V3 neg(V3 a) { return mk(-a.x, -a.y, -a.z); }
+RTR_DEV V3 mul(V3 a, V3 b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z); }
+// cgmath 0.18: dot sums left to right
+RTR_DEV float dot(V3 a, V3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+RTR_DEV V3 cross(V3 a, V3 b) {
+    return mk((a.y * b.z) - (a.z * b.y), (a.z * b.x) - (a.x * b.z), (a.x * b.y) - (a.y * b.x));
+}
+// cgmath normalize = v * (1/|v|)
+RTR_DEV V3 normalize(V3 a) { return scale(a, 1.0f / sqrtf(dot(a, a))); }
+
+constexpr float kPi = 3.14159265358979323846f;
+constexpr float kTMin = 0.00001f; // render.rs:38
+constexpr uint32_t kChainClay = 0xFFFFFFFFu;
+
+// --- counter-based random stream (DESIGN.md "Random numbers") ---------------------------------------
+struct Rng { uint32_t state, inc; };
+RTR_DEV uint32_t hash32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+    return x;
+}
+RTR_DEV uint32_t rng_u32(Rng &r) {
+    uint32_t old = r.state;
+    r.state = old * 747796405u + r.inc;
+    uint32_t word = ((old >> ((old >> 28) + 4u)) ^ old) * 277803737u;
+    return (word >> 22) ^ word;
+}
+// rand 0.8 float conversion: top 23 bits -> k*2^-23
+RTR_DEV float rng_value01(Rng &r) { return (float)(rng_u32(r) >> 9) * 0x1p-23f; }
+RTR_DEV float rng_unit_inclusive(Rng &r) { return rng_value01(r) * 0x1.000002p+0f; } // Uniform::from(0.0..=1.0), render.rs:81
+RTR_DEV float rng_unit(Rng &r) { return rng_value01(r); }                            // gen_range(0.0..1.0), materials.rs:127,151
+RTR_DEV float rng_signed(Rng &r) { return rng_value01(r) * 2.0f + -1.0f; }           // gen_range(-1.0..1.0), sample.rs:29-31
+
+// sample.rs:43-51 rejection-sampled unit ball; returns |v|^2 through m2
+RTR_DEV V3 sample_unit_ball(Rng &rng, float &m2) {
+    V3 v;
+    do {
+        v.x = rng_signed(rng);
+        v.y = rng_signed(rng);
+        v.z = rng_signed(rng);
+        m2 = dot(v, v);
+    } while (!(m2 <= 1.0f));
+    return v;
+}
+// sample.rs:66-70
+RTR_DEV V3 sample_unit_sphere(Rng &rng) {
+    float m2;
+    V3 v = sample_unit_ball(rng, m2);
+    return scale(v, 1.0f / sqrtf(m2));
+}
+
+// --- polynomial acos / atan2 for SkyMap (same sequence as the oracle's OR_TRIG_POLY) -----------------
+RTR_DEV float poly_asin_core(float x) {
+    float z = x * x;
+    float p = 4.2163199048E-2f;
+    p = p * z + 2.4181311049E-2f;
+    p = p * z + 4.5470025998E-2f;
+    p = p * z + 7.4953002686E-2f;
+    p = p * z + 1.6666752422E-1f;
+    return (p * z) * x + x;
+}
+RTR_DEV float poly_acos(float x) {
+    float a = fabsf(x);
+    if (a <= 0.5f) return 1.57079632679489661923f - poly_asin_core(x);
+    float z = (1.0f - a) * 0.5f;
+    float r = 2.0f * poly_asin_core(sqrtf(z));
+    return x > 0.0f ? r : kPi - r;
+}
+RTR_DEV float poly_atan_pos(float x) {
+    float y0 = 0.0f;
+    if (x > 2.414213562373095f) { y0 = 1.57079632679489661923f; x = -(1.0f / x); }
+    else if (x > 0.4142135623730950f) { y0 = 0.78539816339744830962f; x = (x - 1.0f) / (x + 1.0f); }
+    float z = x * x;
+    float p = 8.05374449538e-2f;
+    p = p * z - 1.38776856032E-1f;
+    p = p * z + 1.99777106478E-1f;
+    p = p * z - 3.33329491539E-1f;
+    return y0 + ((p * z) * x + x);
+}
+RTR_DEV float poly_atan2(float y, float x) {
+    if (!(x == x) || !(y == y)) return __builtin_nanf("");
+    if (y == 0.0f) return (x < 0.0f || (x == 0.0f && __builtin_signbit(x))) ? __builtin_copysignf(kPi, y) : y;
+    if (x == 0.0f) return y > 0.0f ? 1.57079632679489661923f : -1.57079632679489661923f;
+    float r = poly_atan_pos(fabsf(y) / fabsf(x));
+    if (x < 0.0f) r = kPi - r;
+    return y < 0.0f ? -r : r;
+}
+
+// Rust `as usize` (backgrounds.rs:88-89): saturating, NaN -> 0
+RTR_DEV unsigned long long sat_usize(float f) {
+    if (!(f == f)) return 0ull;
+    if (f <= 0.0f) return 0ull;
+    if (f >= 18446744073709551616.0f) return ~0ull;
+    return (unsigned long long)f;
+}
+// Rust `as u8` (color.rs:34-41)
+RTR_DEV uint32_t sat_u8(float f) {
+    if (!(f == f)) return 0u;
+    if (f <= 0.0f) return 0u;
+    if (f >= 255.0f) return 255u;
+    return (uint32_t)f;
+}
+
+// --- intersection ------------------------------------------------------------------------------------
+struct Ray { V3 o, d; };
+
+// aabb.rs:81-137 with 1/d hoisted per ray.  Returns hit; *entry = the narrowed tmin.
+RTR_DEV bool slab(const float *bmin, const float *bmax, const Ray &r, V3 inv, float tmax, float &entry) {
+    float tmin = kTMin;
+    bool fail;
+    float t0 = (bmin[0] - r.o.x) * inv.x, t1 = (bmax[0] - r.o.x) * inv.x;
+    if (inv.x < 0.0f) { float t = t0; t0 = t1; t1 = t; }
+    if (t0 > tmin) tmin = t0;
+    if (t1 < tmax) tmax = t1;
+    fail = tmax <= tmin;
+    t0 = (bmin[1] - r.o.y) * inv.y; t1 = (bmax[1] - r.o.y) * inv.y;
+    if (inv.y < 0.0f) { float t = t0; t0 = t1; t1 = t; }
+    if (t0 > tmin) tmin = t0;
+    if (t1 < tmax) tmax = t1;
+    fail = fail || (tmax <= tmin);
+    t0 = (bmin[2] - r.o.z) * inv.z; t1 = (bmax[2] - r.o.z) * inv.z;
+    if (inv.z < 0.0f) { float t = t0; t0 = t1; t1 = t; }
+    if (t0 > tmin) tmin = t0;
+    if (t1 < tmax) tmax = t1;
+    fail = fail || (tmax <= tmin);
+    entry = tmin;
+    return !fail;
+}
+
+// objects.rs:22-51 root selection.  a = |d|^2.  Returns true with t when a root lies in [tmin, tmax].
+RTR_DEV bool sphere_t(V3 c, float r2, const Ray &r, float a, float tmax, float &t) {
+    V3 oc = sub(r.o, c);
+    float half_b = dot(oc, r.d);
+    float cc = dot(oc, oc) - r2;
+    float disc = half_b * half_b - a * cc;
+    if (disc < 0.0f) return false;
+    float sq = sqrtf(disc);
+    float root = (-half_b - sq) / a;
+    if (root < kTMin || tmax < root) {
+        root = (-half_b + sq) / a;
+        if (root < kTMin || tmax < root) return false;
+    }
+    t = root;
+    return true;
+}
+
+// mesh.rs:146-184 Moeller-Trumbore with the reference's tests (tmax ignored).
+RTR_DEV bool triangle_t(V3 v0, V3 e1, V3 e2, const Ray &r, float &t, float &u, float &v) {
+    V3 h = cross(r.d, e2);
+    float a = dot(e1, h);
+    if (a > -kTMin && a < kTMin) return false;
+    float f = 1.0f / a;
+    V3 s = sub(r.o, v0);
+    float uu = f * dot(s, h);
+    if (uu < 0.0f || uu > 1.0f) return false;
+    V3 q = cross(s, e1);
+    float vv = f * dot(r.d, q);
+    if (vv < 0.0f || uu + vv > 1.0f) return false;
+    float tt = f * dot(e2, q);
+    if (!(tt > kTMin)) return false;
+    t = tt; u = uu; v = vv;
+    return true;
+}
+
+struct Best {
+    float t, u, v;
+    uint32_t leaf; // REF_LEAF|type|L, or REF_NONE
+};
+
+// Candidate acceptance inside one tree: the reference merges with `left < right ? left : right`
+// (bvh.rs:181-186): the smaller t wins and the later leaf in depth-first order wins exact ties.
+RTR_DEV bool accept_tree(const Best &b, float t, uint32_t leaf) {
+    return b.leaf == REF_NONE || t < b.t || (t == b.t && (leaf & REF_INDEX) > (b.leaf & REF_INDEX));
+}
+
+RTR_DEV void test_leaf(const RenderParams &p, uint32_t ref, const Ray &r, float a, Best &best) {
+    const float4 *hot = reinterpret_cast<const float4 *>(p.leaf_hot + (ref & REF_INDEX));
+    float4 q0 = hot[0], q1 = hot[1], q2 = hot[2];
+    if (ref & REF_TRI) {
+        float t, u, v;
+        if (triangle_t(mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y), mk(q1.z, q1.w, q2.x), r, t, u, v) &&
+            accept_tree(best, t, ref)) {
+            best.t = t; best.u = u; best.v = v; best.leaf = ref;
+        }
+    } else {
+        float t;
+        // Sphere::hit(ray, tmin, +inf) as called from the tree (bvh.rs:156)
+        if (sphere_t(mk(q0.x, q0.y, q0.z), q1.x, r, a, __builtin_inff(), t) && accept_tree(best, t, ref)) {
+            best.t = t; best.leaf = ref;
+        }
+    }
+}
+
+// BvhNode::hit (bvh.rs:146-172) over the flattened tree rooted at `root`, whose own box has already been
+// tested by the caller.  The reference visits both children of every pierced box with the caller's
+// [tmin,tmax]; here children are visited nearest-entry first and a box is skipped when its entry lies
+// strictly beyond the best hit so far -- nothing inside it can win or tie.
+// tmax_box is the tmax the reference hands to AABB::hit: +inf from the scene tree, closest_so_far when a
+// mesh is reached from the linear world (scene.rs:147, mesh.rs:124-127).
+RTR_DEV void traverse(const RenderParams &p, uint32_t root, const Ray &r, V3 inv, float a, float tmax_box,
+                      Best &best, uint32_t *stk_ref, float *stk_t, uint32_t lane) {
+    uint32_t sp = 0;
+    uint32_t cur = root;
+    for (;;) {
+        bool pop = false;
+        if (cur == REF_NONE) {
+            pop = true;
+        } else if (cur & REF_LEAF) {
+            test_leaf(p, cur, r, a, best);
+            pop = true;
+        } else {
+            const float4 *nq = reinterpret_cast<const float4 *>(p.nodes + cur);
+            float4 q0 = nq[0], q1 = nq[1], q2 = nq[2], q3 = nq[3];
+            float lmin[3] = {q0.x, q0.y, q0.z}, lmax[3] = {q0.w, q1.x, q1.y};
+            float rmin[3] = {q1.z, q1.w, q2.x}, rmax[3] = {q2.y, q2.z, q2.w};
+            uint32_t l = __float_as_uint(q3.x), rr = __float_as_uint(q3.y);
+            bool hl = l != REF_NONE, hr = rr != REF_NONE;
+            float el = 0.0f, er = 0.0f;
+            if (hl && !(l & REF_LEAF)) {
+                hl = slab(lmin, lmax, r, inv, tmax_box, el);
+                if (best.leaf != REF_NONE && el > best.t) hl = false;
+            }
+            if (hr && !(rr & REF_LEAF)) {
+                hr = slab(rmin, rmax, r, inv, tmax_box, er);
+                if (best.leaf != REF_NONE && er > best.t) hr = false;
+            }
+            if (hl && hr) {
+                bool sw = er < el;
+                uint32_t second = sw ? l : rr;
+                float esecond = sw ? el : er;
+                cur = sw ? rr : l;
+                if (sp < p.stack_cap) {
+                    stk_ref[sp * 64 + lane] = second;
+                    stk_t[sp * 64 + lane] = esecond;
+                    sp++;
+                } else {
+                    *p.error_flag = 1u;
+                }
+            } else if (hl) {
+                cur = l;
+            } else if (hr) {
+                cur = rr;
+            } else {
+                pop = true;
+            }
+        }
+        if (pop) {
+            bool got = false;
+            while (sp > 0) {
+                sp--;
+                uint32_t c = stk_ref[sp * 64 + lane];
+                float e = stk_t[sp * 64 + lane];
+                if (best.leaf != REF_NONE && e > best.t) continue;
+                cur = c;
+                got = true;
+                break;
+            }
+            if (!got) break;
+        }
+    }
+}
+
+struct Hit {
+    V3 point, normal;
+    bool front_face;
+    uint32_t material;
+};
+
+// HitRecord::new (ray.rs:39-54)
+RTR_DEV void face_forward(Hit &h, const Ray &r, V3 outward) {
+    h.front_face = dot(r.d, outward) < 0.0f;
+    h.normal = h.front_face ? outward : neg(outward);
+}
+
+// Build the HitRecord of the winning leaf (objects.rs:45-48 | mesh.rs:185-193).
+RTR_DEV void finish_leaf(const RenderParams &p, const Best &best, const Ray &r, Hit &h) {
+    uint32_t L = best.leaf & REF_INDEX;
+    const float4 *cold = reinterpret_cast<const float4 *>(p.leaf_cold + L);
+    h.point = add(r.o, scale(r.d, best.t));
+    float4 c0 = cold[0];
+    h.material = __float_as_uint(c0.w);
+    if (best.leaf & REF_TRI) {
+        float4 c1 = cold[1], c2 = cold[2], c3 = cold[3];
+        V3 n0 = mk(c0.x, c0.y, c0.z), n1 = mk(c1.x, c1.y, c1.z), n2 = mk(c2.x, c2.y, c2.z), fn = mk(c3.x, c3.y, c3.z);
+        float u = best.u, v = best.v;
+        V3 n = add(add(scale(n1, u), scale(n2, v)), scale(n0, 1.0f - u - v));
+        // mesh.rs:187: normal.angle(face) > 0 with cgmath angle = atan2(|n x f|, n.f)
+        V3 cr = cross(n, fn);
+        float mag = sqrtf(dot(cr, cr));
+        float dd = dot(n, fn);
+        bool use_face = (mag > 0.0f) || (mag == 0.0f && (dd < 0.0f || (dd == 0.0f && __builtin_signbit(dd))));
+        if (use_face) n = fn;
+        face_forward(h, r, n);
+    } else {
+        const float4 *hot = reinterpret_cast<const float4 *>(p.leaf_hot + L);
+        float4 q0 = hot[0];
+        V3 outward = divs(sub(h.point, mk(q0.x, q0.y, q0.z)), q0.w);
+        face_forward(h, r, outward);
+    }
+}
+
+// world.hit (render.rs:38).  Returns false on miss.
+template <uint32_t WORLD>
+RTR_DEV bool world_hit(const RenderParams &p, const Ray &r, Hit &h, uint32_t *stk_ref, float *stk_t, uint32_t lane) {
+    const float a = dot(r.d, r.d); // objects.rs:25, hoisted per ray
+    if constexpr (WORLD == WORLD_LINEAR_SPHERES) {
+        // scene.rs:141-157: ordered scan, closest_so_far shrinks, later object wins exact ties
+        float closest = __builtin_inff();
+        int best = -1;
+        for (uint32_t i = 0; i < p.n_objects; i++) {
+            const DevLinSphere &s = p.lin_spheres[i]; // wave-uniform address: scalar loads
+            float t;
+            if (sphere_t(mk(s.center[0], s.center[1], s.center[2]), s.radius2, r, a, closest, t)) {
+                closest = t;
+                best = (int)i;
+            }
+        }
+        if (best < 0) return false;
+        const DevLinSphere &s = p.lin_spheres[best];
+        h.point = add(r.o, scale(r.d, closest));
+        V3 outward = divs(sub(h.point, mk(s.center[0], s.center[1], s.center[2])), s.radius);
+        face_forward(h, r, outward);
+        h.material = s.material;
+        return true;
+    } else {
+        const V3 inv = mk(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z); // aabb.rs:86,103,120, hoisted per ray
+        Best best;
+        best.leaf = REF_NONE; best.t = __builtin_inff(); best.u = 0.0f; best.v = 0.0f;
+        if constexpr (WORLD == WORLD_BVH) {
+            uint32_t root = p.root_ref;
+            bool go = root != REF_NONE;
+            if (go && !(root & REF_LEAF)) {
+                float e;
+                go = slab(p.root_box, p.root_box + 3, r, inv, __builtin_inff(), e);
+            }
+            if (go) traverse(p, root, r, inv, a, __builtin_inff(), best, stk_ref, stk_t, lane);
+        } else {
+            // scene.rs:141-157 with meshes: object.hit(ray, tmin, closest_so_far); a mesh returns the nearest
+            // triangle of the boxes that pass AABB::hit(.., closest_so_far) and Triangle::hit ignores tmax
+            // (mesh.rs:151), so a mesh hit replaces the result unconditionally.
+            float closest = __builtin_inff();
+            for (uint32_t i = 0; i < p.n_objects; i++) {
+                const DevObject &o = p.objects[i];
+                uint32_t ref = o.ref;
+                if (ref == REF_NONE) continue;
+                if ((ref & REF_LEAF) && !(ref & REF_TRI)) {
+                    const float4 *hot = reinterpret_cast<const float4 *>(p.leaf_hot + (ref & REF_INDEX));
+                    float4 q0 = hot[0], q1 = hot[1];
+                    float t;
+                    if (sphere_t(mk(q0.x, q0.y, q0.z), q1.x, r, a, closest, t)) {
+                        closest = t; best.t = t; best.leaf = ref;
+                    }
+                } else {
+                    Best local;
+                    local.leaf = REF_NONE; local.t = __builtin_inff(); local.u = 0.0f; local.v = 0.0f;
+                    bool go = true;
+                    if (!(ref & REF_LEAF)) {
+                        float e;
+                        go = slab(o.box, o.box + 3, r, inv, closest, e);
+                    }
+                    if (go) traverse(p, ref, r, inv, a, closest, local, stk_ref, stk_t, lane);
+                    if (local.leaf != REF_NONE) {
+                        closest = local.t;
+                        best = local;
+                    }
+                }
+            }
+        }
+        if (best.leaf == REF_NONE) return false;
+        finish_leaf(p, best, r, h);
+        return true;
+    }
+}
+
+// --- shading -----------------------------------------------------------------------------------------
+RTR_DEV bool near_zero(V3 v) { // math.rs:6-9
+    const float eps = 1.0e-8f;
+    return fabsf(v.x) < eps && fabsf(v.y) < eps && fabsf(v.z) < eps;
+}
+RTR_DEV V3 reflect(V3 v, V3 n) { return sub(v, scale(n, 2.0f * dot(v, n))); } // math.rs:12-14
+RTR_DEV V3 refract(V3 uv, V3 n, float eta) {                                    // math.rs:16-21
+    float cos_theta = fminf(dot(n, neg(uv)), 1.0f);
+    V3 out_perp = scale(add(uv, scale(n, cos_theta)), eta);
+    V3 out_parallel = scale(n, -sqrtf(fabsf(1.0f - dot(out_perp, out_perp))));
+    return add(out_perp, out_parallel);
+}
+RTR_DEV float reflectance(float cosine, float idx) { // materials.rs:103-108; powi(x,5) = x*((x*x)*(x*x))
+    float r0 = (1.0f - idx) / (1.0f + idx);
+    r0 = r0 * r0;
+    float x = 1.0f - cosine;
+    float x2 = x * x;
+    float x4 = x2 * x2;
+    return r0 + (1.0f - r0) * (x * x4);
+}
+
+RTR_DEV V3 material_rgb(const RenderParams &p, uint32_t id) {
+    if (id == kChainClay) return mk(0.8f, 0.8f, 0.8f);
+    const float4 *m = reinterpret_cast<const float4 *>(p.materials + id);
+    float4 q = m[0];
+    return mk(q.x, q.y, q.z);
+}
+
+// Background::sample (backgrounds.rs)
+RTR_DEV V3 background(const RenderParams &p, const Ray &r) {
+    if (p.bg_kind == 0u) return ld3(p.bg_a); // backgrounds.rs:25-30
+    if (p.bg_kind == 1u) {                   // backgrounds.rs:44-49, ray.rs:19-26
+        float t = 0.5f * (normalize(r.d).y + 1.0f);
+        return add(scale(ld3(p.bg_a), 1.0f - t), scale(ld3(p.bg_b), t));
+    }
+    // backgrounds.rs:84-92, math.rs:24-29: nearest texel of an equirectangular image
+    V3 d = normalize(r.d);
+    float sx = poly_acos(-d.y);
+    float sy = poly_atan2(-d.z, d.x) + kPi;
+    float u = sx / kPi;
+    float v = sy / (2.0f * kPi);
+    unsigned long long x = sat_usize(v * (float)p.sky_w) % p.sky_w;
+    unsigned long long y = (unsigned long long)p.sky_h - 1ull - sat_usize(u * (float)p.sky_h) % p.sky_h;
+    float4 texel = reinterpret_cast<const float4 *>(p.sky)[x + y * p.sky_w];
+    return mk(texel.x, texel.y, texel.z);
+}
+
+// One wave = one 8x8 tile.  LDS (dynamic): [chain: max_depth x 64 u32][stack refs: cap x 64][stack t: cap x 64]
+template <uint32_t WORLD>
+__global__ __launch_bounds__(64) void k_render(const RenderParams p) {
+    extern __shared__ uint32_t lds[];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t tile = blockIdx.x * p.n_shards + p.shard;
+    if (tile >= p.tiles_total) return;
+    uint32_t *chain = lds;
+    uint32_t *stk_ref = lds + p.max_depth * 64u;
+    float *stk_t = reinterpret_cast<float *>(stk_ref + p.stack_cap * 64u);
+
+    const uint32_t tx = tile % p.tiles_x, ty = tile / p.tiles_x;
+    const uint32_t x = tx * 8u + (lane & 7u), y = ty * 8u + (lane >> 3);
+    const bool inside = x < p.width && y < p.height;
+    const uint32_t pixel = y * p.width + x; // render.rs:76-77: index = y*W + x
+    const float fx = (float)x, fy = (float)y;
+
+    const V3 cam_o = ld3(p.cam_origin), cam_h = ld3(p.cam_horizontal), cam_v = ld3(p.cam_vertical), cam_llc = ld3(p.cam_llc);
+
+    // per-pixel stream constants
+    const uint32_t hp = hash32(pixel ^ p.seed_lo);
+    Rng rng;
+    rng.inc = (hash32(hp + p.seed_hi) << 1) | 1u;
+    rng.state = 0u;
+
+    V3 acc = mk(0.0f, 0.0f, 0.0f);
+    uint32_t nseg = 0;
+    const uint32_t spp = (inside && p.max_depth > 0u) ? p.spp : 0u;
+    uint32_t s = 0, depth = 0, nchain = 0;
+    Ray ray;
+    ray.o = cam_o; ray.d = cam_o;
+
+    auto start_sample = [&](uint32_t si) {
+        rng.state = hash32(hp + si * 0x9E3779B9u);
+        // render.rs:88-89
+        float u = (fx + rng_unit_inclusive(rng)) / p.width_m1;
+        float v = (fy + rng_unit_inclusive(rng)) / p.height_m1;
+        // camera.rs:19-24
+        ray.o = cam_o;
+        ray.d = sub(sub(add(cam_llc, scale(cam_h, u)), scale(cam_v, v)), cam_o);
+        depth = 0; nchain = 0;
+    };
+    if (spp > 0u) start_sample(0u);
+
+    while (s < spp) {
+        // ---- trace_ray body (render.rs:32-59): one segment ----
+        Hit h;
+        nseg++;
+        bool done;
+        V3 term;
+        if (!world_hit<WORLD>(p, ray, h, stk_ref, stk_t, lane)) {
+            term = background(p, ray);
+            done = true;
+        } else if (p.mode == 3u) { // RenderMode::Normal, render.rs:42-45
+            V3 n = scale(add(normalize(h.normal), mk(1.0f, 1.0f, 1.0f)), 0.5f);
+            term = n;
+            done = true;
+        } else if (p.mode == 2u) { // RenderMode::Random, render.rs:46-48
+            term = mk(0.0f, 0.0f, 0.0f);
+            done = true;
+        } else {
+            uint32_t kind, mid = h.material;
+            float param = 0.0f;
+            V3 rgb = mk(0.8f, 0.8f, 0.8f);
+            if (p.mode == 1u) { // RenderMode::Clay: Lambertian(0.8) (render.rs:41)
+                kind = 0u; mid = kChainClay;
+            } else {
+                // MixMaterial::scatter (materials.rs:148-157): xi >= factor -> first
+                for (;;) {
+                    const float4 *m = reinterpret_cast<const float4 *>(p.materials + mid);
+                    float4 q0 = m[0], q1 = m[1];
+                    kind = __float_as_uint(q1.x);
+                    rgb = mk(q0.x, q0.y, q0.z);
+                    param = q0.w;
+                    if (kind != 4u) break;
+                    mid = (rng_unit(rng) >= param) ? __float_as_uint(q1.y) : __float_as_uint(q1.z);
+                }
+            }
+            bool scattered = true;
+            V3 ndir = h.normal;
+            if (kind == 0u) { // Lambertian, materials.rs:31-41
+                ndir = add(h.normal, sample_unit_sphere(rng));
+                if (near_zero(ndir)) ndir = h.normal;
+            } else if (kind == 1u) { // Metal, materials.rs:58-70
+                V3 reflected = normalize(reflect(ray.d, h.normal));
+                ndir = add(reflected, scale(sample_unit_sphere(rng), param));
+                if (!(dot(ndir, h.normal) > 0.0f)) { scattered = false; term = mk(0.0f, 0.0f, 0.0f); }
+            } else if (kind == 2u) { // Emission, materials.rs:86-91
+                scattered = false; term = rgb;
+            } else if (kind == 3u) { // Dielectric, materials.rs:111-138
+                float ratio = h.front_face ? 1.0f / param : param;
+                V3 unit = normalize(ray.d);
+                float cos_theta = fminf(dot(h.normal, neg(unit)), 1.0f);
+                float sin_theta = sqrtf(1.0f - cos_theta * cos_theta);
+                bool cannot_refract = (ratio * sin_theta) > 1.0f;
+                bool refl = cannot_refract;
+                if (!refl) refl = reflectance(cos_theta, ratio) > rng_unit(rng); // no draw on TIR (short-circuit ||)
+                ndir = refl ? reflect(unit, h.normal) : refract(unit, h.normal, ratio);
+                mid = 0xFFFFFFFEu; // attenuation (1,1,1): x*1 == x exactly, nothing to replay
+            } else { // Isotropic, volume.rs:80-88
+                float m2;
+                ndir = sample_unit_ball(rng, m2);
+            }
+            if (scattered) {
+                if (mid != 0xFFFFFFFEu) { chain[nchain * 64u + lane] = mid; nchain++; }
+                ray.o = h.point;
+                ray.d = ndir;
+                depth++;
+                done = depth >= p.max_depth; // render.rs:34-36
+                term = mk(0.0f, 0.0f, 0.0f);
+            } else {
+                done = true;
+            }
+        }
+        if (done) {
+            // attenuation * (attenuation * (... * terminal)), render.rs:52
+            while (nchain > 0u) {
+                nchain--;
+                term = mul(material_rgb(p, chain[nchain * 64u + lane]), term);
+            }
+            // f32::clamp(0, clamp_indirect), NaN stays NaN (render.rs:95-97)
+            const float hi = p.clamp_indirect;
+            if (term.x < 0.0f) term.x = 0.0f;
+            if (term.x > hi) term.x = hi;
+            if (term.y < 0.0f) term.y = 0.0f;
+            if (term.y > hi) term.y = hi;
+            if (term.z < 0.0f) term.z = 0.0f;
+            if (term.z > hi) term.z = hi;
+            acc = add(acc, term); // render.rs:99
+            s++;
+            if (s < spp) start_sample(s);
+        }
+    }
+
+    if (inside) {
+        if (p.sum_rgba) {
+            reinterpret_cast<float4 *>(p.sum_rgba)[pixel] = make_float4(acc.x, acc.y, acc.z, 0.0f);
+        }
+        if (p.rgba8 || p.mean_rgb) {
+            // render.rs:103-110
+            const float n = (float)p.spp;
+            V3 mean = mk(acc.x / n, acc.y / n, acc.z / n);
+            if (p.mean_rgb) {
+                p.mean_rgb[3ull * pixel + 0] = mean.x;
+                p.mean_rgb[3ull * pixel + 1] = mean.y;
+                p.mean_rgb[3ull * pixel + 2] = mean.z;
+            }
+            if (p.rgba8) {
+                uint32_t r8 = sat_u8(sqrtf(mean.x) * 255.0f), g8 = sat_u8(sqrtf(mean.y) * 255.0f),
+                         b8 = sat_u8(sqrtf(mean.z) * 255.0f);
+                reinterpret_cast<uint32_t *>(p.rgba8)[pixel] = r8 | (g8 << 8) | (b8 << 16) | (255u << 24);
+            }
+        }
+    }
+
+    // one atomic per wave
+    unsigned long long total = nseg;
+    for (int off = 32; off > 0; off >>= 1) total += __shfl_xor(total, off, 64);
+    if (lane == 0 && total) atomicAdd(p.counter, total);
+}
+
+// render.rs:103-110 for the sharded path: sum -> mean -> sqrt -> RGBA8
+__global__ __launch_bounds__(256) void k_resolve(const float *sum_rgba, uint32_t spp, uint32_t n_pixels, uint8_t *rgba8,
+                                                 float *mean_rgb) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pixels) return;
+    float4 s = reinterpret_cast<const float4 *>(sum_rgba)[i];
+    const float n = (float)spp;
+    float r = s.x / n, g = s.y / n, b = s.z / n;
+    if (mean_rgb) {
+        mean_rgb[3ull * i + 0] = r;
+        mean_rgb[3ull * i + 1] = g;
+        mean_rgb[3ull * i + 2] = b;
+    }
+    if (rgba8) {
+        uint32_t r8 = sat_u8(sqrtf(r) * 255.0f), g8 = sat_u8(sqrtf(g) * 255.0f), b8 = sat_u8(sqrtf(b) * 255.0f);
+        reinterpret_cast<uint32_t *>(rgba8)[i] = r8 | (g8 << 8) | (b8 << 16) | (255u << 24);
+    }
+}
+
+// --- launchers (called from rtr_api.cpp) -----------------------------------------------------------------
+hipError_t launch_render(const RenderParams &p, uint32_t grid, uint32_t lds_bytes, hipStream_t stream) {
+    switch (p.world) {
+    case WORLD_LINEAR_SPHERES: hipLaunchKernelGGL(k_render<WORLD_LINEAR_SPHERES>, dim3(grid), dim3(64), lds_bytes, stream, p); break;
+    case WORLD_BVH: hipLaunchKernelGGL(k_render<WORLD_BVH>, dim3(grid), dim3(64), lds_bytes, stream, p); break;
+    default: hipLaunchKernelGGL(k_render<WORLD_LINEAR_GENERIC>, dim3(grid), dim3(64), lds_bytes, stream, p); break;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_resolve(const float *sum_rgba, uint32_t spp, uint32_t n_pixels, uint8_t *rgba8, float *mean_rgb,
+                          hipStream_t stream) {
+    uint32_t grid = (n_pixels + 255u) / 256u;
+    hipLaunchKernelGGL(k_resolve, dim3(grid), dim3(256), 0, stream, sum_rgba, spp, n_pixels, rgba8, mean_rgb);
+    return hipGetLastError();
+}
+
+hipError_t render_kernel_attributes(uint32_t world, int *vgprs, int *static_lds) {
+    hipFuncAttributes attr;
+    hipError_t e;
+    switch (world) {
+    case WORLD_LINEAR_SPHERES: e = hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(k_render<WORLD_LINEAR_SPHERES>)); break;
+    case WORLD_BVH: e = hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(k_render<WORLD_BVH>)); break;
+    default: e = hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(k_render<WORLD_LINEAR_GENERIC>)); break;
+    }
+    if (e == hipSuccess) { *vgprs = attr.numRegs; *static_lds = (int)attr.sharedSizeBytes; }
+    return e;
+}
+
+} // namespace rtr

@@ -1,0 +1,411 @@
+// rtr_scene.cpp -- scene lowering, the reference's BVH builder and the flattener (host, no HIP).
+//
+// The tree SHAPE is part of the contract: exact-t ties resolve by depth-first leaf order (bvh.rs:181-186)
+// and the set of boxes decides which triangles are ever tested, so the builder reproduces
+// BvhNode::from_list (lib/core/bvh.rs:59-144) decision for decision:
+//   bounds   = reduce(surround) over the members' bounds, seeded by the first member (bvh.rs:66-70)
+//   axis     = x iff sx>sy && sx>sz; else y iff sy>sx && sy>sz; else z, s = spread of the member-bounds
+//              centroids (bvh.rs:73-87)
+//   order    = stable ascending sort on centroid[axis] (bvh.rs:90-123); NaN -> the reference panics
+//   split    = first floor(n/2) members left, rest right (bvh.rs:126-135); n==1 -> leaf, n==0 -> None
+// Built with -ffp-contract=off: bounds, centroids, edges and face normals must round as the reference's f32.
+#include "rtr_scene.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <numeric>
+
+namespace rtr {
+namespace {
+
+struct Box {
+    float mn[3], mx[3];
+};
+
+// AABB::surround (lib/utils/aabb.rs:41-54): f32::min / f32::max per component
+inline Box surround(const Box &a, const Box &b) {
+    Box r;
+    for (int k = 0; k < 3; k++) {
+        r.mn[k] = std::fmin(a.mn[k], b.mn[k]);
+        r.mx[k] = std::fmax(a.mx[k], b.mx[k]);
+    }
+    return r;
+}
+inline Box point_box(const float *p) {
+    Box r;
+    for (int k = 0; k < 3; k++) r.mn[k] = r.mx[k] = p[k];
+    return r;
+}
+// AABB::centroid (aabb.rs:28-30)
+inline float centroid(const Box &b, int k) { return (b.mn[k] + b.mx[k]) / 2.0f; }
+
+// AABB::epsilon_expand (aabb.rs:57-78)
+inline Box epsilon_expand(const Box &b, float eps) {
+    Box r = b;
+    for (int k = 0; k < 3; k++) {
+        float dim = b.mx[k] - b.mn[k];
+        float c = centroid(b, k);
+        if (dim < eps) {
+            r.mn[k] = c - eps;
+            r.mx[k] = c + eps;
+        }
+    }
+    return r;
+}
+
+enum : uint8_t { T_NONE = 0, T_LEAF = 1, T_SPLIT = 2 };
+struct TreeNode {
+    uint8_t kind = T_NONE;
+    uint32_t handle = 0;
+    Box box{};
+    int32_t left = -1, right = -1;
+};
+
+// One BoundsCollection (bvh.rs:18-28) reduced to what the builder reads: bounds(handle).
+struct Tree {
+    std::vector<TreeNode> nodes;
+    int32_t root = -1;
+};
+
+class Builder {
+  public:
+    Builder(const std::vector<Box> &bounds, Tree &tree) : bounds_(bounds), tree_(tree) {}
+    bool nan_seen = false;
+
+    int32_t build(std::vector<uint32_t> &h, size_t b, size_t e) {
+        int32_t id = (int32_t)tree_.nodes.size();
+        tree_.nodes.emplace_back();
+        size_t n = e - b;
+        if (n == 0) return id;
+        if (n == 1) {
+            tree_.nodes[id].kind = T_LEAF;
+            tree_.nodes[id].handle = h[b];
+            return id;
+        }
+        Box all = bounds_[h[b]];
+        for (size_t i = b + 1; i < e; i++) all = surround(all, bounds_[h[i]]);
+        float cmin[3], cmax[3];
+        for (int k = 0; k < 3; k++) cmin[k] = cmax[k] = centroid(bounds_[h[b]], k);
+        for (size_t i = b + 1; i < e; i++)
+            for (int k = 0; k < 3; k++) {
+                float c = centroid(bounds_[h[i]], k);
+                cmin[k] = std::fmin(cmin[k], c);
+                cmax[k] = std::fmax(cmax[k], c);
+            }
+        float sx = cmax[0] - cmin[0], sy = cmax[1] - cmin[1], sz = cmax[2] - cmin[2];
+        int axis = (sx > sy && sx > sz) ? 0 : ((sy > sx && sy > sz) ? 1 : 2);
+        for (size_t i = b; i < e; i++) {
+            float c = centroid(bounds_[h[i]], axis);
+            if (c != c) nan_seen = true;
+        }
+        if (!nan_seen)
+            std::stable_sort(h.begin() + (ptrdiff_t)b, h.begin() + (ptrdiff_t)e, [&](uint32_t p, uint32_t q) {
+                return centroid(bounds_[p], axis) < centroid(bounds_[q], axis);
+            });
+        size_t mid = b + n / 2;
+        int32_t l = build(h, b, mid);
+        int32_t r = build(h, mid, e);
+        TreeNode &nd = tree_.nodes[id];
+        nd.kind = T_SPLIT;
+        nd.box = all;
+        nd.left = l;
+        nd.right = r;
+        return id;
+    }
+
+  private:
+    const std::vector<Box> &bounds_;
+    Tree &tree_;
+};
+
+struct MeshBuild {
+    Tree tree;
+    std::vector<DevLeafHot> hot;   // per triangle handle
+    std::vector<DevLeafCold> cold; // per triangle handle
+    Box bounds;                    // Mesh.bounds, mesh.rs:99-108
+};
+
+inline void sub3(const float *a, const float *b, float *o) {
+    o[0] = a[0] - b[0];
+    o[1] = a[1] - b[1];
+    o[2] = a[2] - b[2];
+}
+inline void cross3(const float *a, const float *b, float *o) { // cgmath Vector3::cross
+    o[0] = (a[1] * b[2]) - (a[2] * b[1]);
+    o[1] = (a[2] * b[0]) - (a[0] * b[2]);
+    o[2] = (a[0] * b[1]) - (a[1] * b[0]);
+}
+
+struct Flattener {
+    const rtr_scene_desc &desc;
+    const std::vector<MeshBuild> &meshes;
+    const Tree &scene_tree;
+    FlatScene &out;
+    std::vector<uint32_t> &obj_ref;    // per object: ref of its leaf / subtree root
+    std::vector<Box> &obj_box;         // per object: box of that root when it is a Split
+    std::vector<uint32_t> &obj_height; // per object: Split nodes on its longest root-to-leaf path
+
+    // Box of a flattened ref's own Split node, needed by its parent.
+    struct Emitted {
+        uint32_t ref;
+        Box box;
+        uint32_t height;
+    };
+
+    Emitted emit_sphere(uint32_t object, const rtr_sphere &s) {
+        uint32_t L = (uint32_t)out.leaf_hot.size();
+        DevLeafHot hot{};
+        hot.f[0] = s.center[0]; hot.f[1] = s.center[1]; hot.f[2] = s.center[2]; hot.f[3] = s.radius;
+        hot.f[4] = s.radius * s.radius; // objects.rs:27 `self.radius * self.radius`
+        DevLeafCold cold{};
+        cold.material = s.material; cold.object = object; cold.handle = 0;
+        out.leaf_hot.push_back(hot);
+        out.leaf_cold.push_back(cold);
+        return {REF_LEAF | L, Box{}, 0};
+    }
+
+    Emitted emit_mesh_node(uint32_t object, const MeshBuild &mb, int32_t ni) {
+        const TreeNode &n = mb.tree.nodes[ni];
+        if (n.kind == T_NONE) return {REF_NONE, Box{}, 0};
+        if (n.kind == T_LEAF) {
+            uint32_t L = (uint32_t)out.leaf_hot.size();
+            out.leaf_hot.push_back(mb.hot[n.handle]);
+            DevLeafCold c = mb.cold[n.handle];
+            c.object = object;
+            out.leaf_cold.push_back(c);
+            return {REF_LEAF | REF_TRI | L, Box{}, 0};
+        }
+        uint32_t idx = (uint32_t)out.nodes.size();
+        out.nodes.emplace_back();
+        Emitted l = emit_mesh_node(object, mb, n.left);
+        Emitted r = emit_mesh_node(object, mb, n.right);
+        fill_node(idx, l, r);
+        return {idx, n.box, 1 + std::max(l.height, r.height)};
+    }
+
+    Emitted emit_object(uint32_t object) {
+        const rtr_object &o = desc.objects[object];
+        Emitted e;
+        if (o.kind == RTR_OBJ_SPHERE) {
+            e = emit_sphere(object, desc.spheres[o.index]);
+        } else {
+            const MeshBuild &mb = meshes[o.index];
+            e = emit_mesh_node(object, mb, mb.tree.root); // Mesh::hit = bvh_root.hit, mesh.rs:124-127
+        }
+        obj_ref[object] = e.ref;
+        obj_box[object] = e.box;
+        obj_height[object] = e.height;
+        return e;
+    }
+
+    Emitted emit_scene_node(int32_t ni) {
+        const TreeNode &n = scene_tree.nodes[ni];
+        if (n.kind == T_NONE) return {REF_NONE, Box{}, 0};
+        if (n.kind == T_LEAF) return emit_object(n.handle);
+        uint32_t idx = (uint32_t)out.nodes.size();
+        out.nodes.emplace_back();
+        Emitted l = emit_scene_node(n.left);
+        Emitted r = emit_scene_node(n.right);
+        fill_node(idx, l, r);
+        return {idx, n.box, 1 + std::max(l.height, r.height)};
+    }
+
+    void fill_node(uint32_t idx, const Emitted &l, const Emitted &r) {
+        DevNode &d = out.nodes[idx];
+        std::memset(&d, 0, sizeof d);
+        for (int k = 0; k < 3; k++) {
+            d.lmin[k] = l.box.mn[k]; d.lmax[k] = l.box.mx[k];
+            d.rmin[k] = r.box.mn[k]; d.rmax[k] = r.box.mx[k];
+        }
+        d.lref = l.ref;
+        d.rref = r.ref;
+    }
+};
+
+} // namespace
+
+int build_flat_scene(const rtr_scene_desc &desc, FlatScene &out, std::string &err) {
+    out = FlatScene{};
+    if ((desc.n_objects && !desc.objects) || (desc.n_spheres && !desc.spheres) || (desc.n_meshes && !desc.meshes) ||
+        (desc.n_materials && !desc.materials)) {
+        err = "null array with non-zero count in rtr_scene_desc";
+        return RTR_ERR_INVALID_ARGUMENT;
+    }
+    // ---- materials (scene.rs:100-110) ----
+    out.materials.resize(desc.n_materials);
+    for (uint32_t i = 0; i < desc.n_materials; i++) {
+        const rtr_material &m = desc.materials[i];
+        if (m.kind > RTR_MAT_ISOTROPIC) { err = "unknown material kind"; return RTR_ERR_INVALID_ARGUMENT; }
+        DevMaterial d{};
+        d.rgb[0] = m.rgb[0]; d.rgb[1] = m.rgb[1]; d.rgb[2] = m.rgb[2];
+        d.param = m.param; d.kind = m.kind; d.first = m.first; d.second = m.second;
+        if (m.kind == RTR_MAT_MIX) {
+            // nested boxes flattened to indices; children after the parent so the device walk terminates
+            if (m.first >= desc.n_materials || m.second >= desc.n_materials) { err = "mix child out of bounds"; return RTR_ERR_BAD_INDEX; }
+            if (m.first <= i || m.second <= i) { err = "mix children must follow their parent in the materials array"; return RTR_ERR_INVALID_ARGUMENT; }
+        }
+        out.materials[i] = d;
+    }
+    // ---- background (backgrounds.rs) ----
+    const rtr_background &bg = desc.background;
+    out.bg_kind = bg.kind;
+    for (int k = 0; k < 3; k++) { out.bg_a[k] = bg.a[k]; out.bg_b[k] = bg.b[k]; }
+    if (bg.kind == RTR_BG_SKYMAP) {
+        if (!bg.image || bg.width == 0 || bg.height == 0) { err = "empty sky image (% width panics, backgrounds.rs:88)"; return RTR_ERR_INVALID_ARGUMENT; }
+        size_t n = (size_t)bg.width * bg.height;
+        out.sky.resize(n * 4);
+        for (size_t i = 0; i < n; i++) {
+            out.sky[4 * i + 0] = bg.image[3 * i + 0];
+            out.sky[4 * i + 1] = bg.image[3 * i + 1];
+            out.sky[4 * i + 2] = bg.image[3 * i + 2];
+            out.sky[4 * i + 3] = 0.0f;
+        }
+        out.sky_w = bg.width; out.sky_h = bg.height;
+    } else if (bg.kind > RTR_BG_SKYMAP) {
+        err = "unknown background kind";
+        return RTR_ERR_INVALID_ARGUMENT;
+    }
+
+    // ---- meshes: Mesh::from_buffers + build_bvh (mesh.rs:78-121) ----
+    std::vector<MeshBuild> meshes(desc.n_meshes);
+    for (uint32_t mi = 0; mi < desc.n_meshes; mi++) {
+        const rtr_mesh &m = desc.meshes[mi];
+        MeshBuild &mb = meshes[mi];
+        if ((m.n_verts && (!m.positions || !m.normals)) || (m.n_tris && !m.indices)) { err = "null mesh buffer"; return RTR_ERR_INVALID_ARGUMENT; }
+        if (m.material >= desc.n_materials) { err = "mesh material out of bounds"; return RTR_ERR_BAD_INDEX; }
+        if (m.n_tris > REF_INDEX) { err = "too many triangles"; return RTR_ERR_INVALID_ARGUMENT; }
+        for (uint64_t i = 0; i < 3ull * m.n_tris; i++)
+            if (m.indices[i] >= m.n_verts) { err = "vertex index out of bounds (mesh.rs:84-88 panics)"; return RTR_ERR_BAD_INDEX; }
+        mb.hot.resize(m.n_tris);
+        mb.cold.resize(m.n_tris);
+        std::vector<Box> tb(m.n_tris);
+        for (uint32_t t = 0; t < m.n_tris; t++) {
+            const uint32_t *ix = m.indices + 3ull * t;
+            const float *p0 = m.positions + 3ull * ix[0], *p1 = m.positions + 3ull * ix[1], *p2 = m.positions + 3ull * ix[2];
+            DevLeafHot &h = mb.hot[t];
+            std::memset(&h, 0, sizeof h);
+            float e1[3], e2[3];
+            sub3(p1, p0, e1); // mesh.rs:160
+            sub3(p2, p0, e2); // mesh.rs:161
+            h.f[0] = p0[0]; h.f[1] = p0[1]; h.f[2] = p0[2];
+            h.f[3] = e1[0]; h.f[4] = e1[1]; h.f[5] = e1[2];
+            h.f[6] = e2[0]; h.f[7] = e2[1]; h.f[8] = e2[2];
+            // face normal, mesh.rs:86-90: ((v2-v1) x (v0-v1)).normalize()
+            float a[3], b[3], c[3];
+            sub3(p0, p1, a);
+            sub3(p2, p1, b);
+            cross3(b, a, c);
+            float inv = 1.0f / std::sqrt((c[0] * c[0] + c[1] * c[1]) + c[2] * c[2]);
+            DevLeafCold &cd = mb.cold[t];
+            std::memset(&cd, 0, sizeof cd);
+            cd.fn[0] = c[0] * inv; cd.fn[1] = c[1] * inv; cd.fn[2] = c[2] * inv;
+            const float *n0 = m.normals + 3ull * ix[0], *n1 = m.normals + 3ull * ix[1], *n2 = m.normals + 3ull * ix[2];
+            for (int k = 0; k < 3; k++) { cd.n0[k] = n0[k]; cd.n1[k] = n1[k]; cd.n2[k] = n2[k]; }
+            cd.material = m.material;
+            cd.handle = t;
+            // BoundsCollection::bounds for Mesh, mesh.rs:201-213
+            tb[t] = epsilon_expand(surround(point_box(p0), surround(point_box(p1), point_box(p2))), 0.01f);
+        }
+        // Mesh.bounds seeded with the zero box (mesh.rs:99-108, aabb.rs:140-147)
+        Box mbounds{};
+        for (uint32_t v = 0; v < m.n_verts; v++) mbounds = surround(mbounds, point_box(m.positions + 3ull * v));
+        mb.bounds = mbounds;
+        std::vector<uint32_t> handles(m.n_tris);
+        std::iota(handles.begin(), handles.end(), 0u);
+        Builder b(tb, mb.tree);
+        mb.tree.root = b.build(handles, 0, handles.size());
+        if (b.nan_seen) { err = "NaN triangle centroid: partial_cmp().unwrap() panics (bvh.rs:99,109,119)"; return RTR_ERR_NAN_CENTROID; }
+    }
+
+    // ---- scene-level collection (scene.rs:117-139) ----
+    std::vector<Box> ob(desc.n_objects);
+    for (uint32_t i = 0; i < desc.n_objects; i++) {
+        const rtr_object &o = desc.objects[i];
+        if (o.kind == RTR_OBJ_SPHERE) {
+            if (o.index >= desc.n_spheres) { err = "sphere index out of bounds"; return RTR_ERR_BAD_INDEX; }
+            const rtr_sphere &s = desc.spheres[o.index];
+            if (s.material >= desc.n_materials) { err = "sphere material out of bounds (scene.rs:106-110 panics)"; return RTR_ERR_BAD_INDEX; }
+            for (int k = 0; k < 3; k++) { // Sphere::bounds, objects.rs:53-60
+                ob[i].mn[k] = s.center[k] - s.radius;
+                ob[i].mx[k] = s.center[k] + s.radius;
+            }
+        } else if (o.kind == RTR_OBJ_MESH) {
+            if (o.index >= desc.n_meshes) { err = "mesh index out of bounds"; return RTR_ERR_BAD_INDEX; }
+            ob[i] = meshes[o.index].bounds; // Bounded for Mesh, mesh.rs:234-238
+            out.spheres_only = false;
+        } else {
+            err = "unknown object kind";
+            return RTR_ERR_INVALID_ARGUMENT;
+        }
+    }
+    Tree scene_tree;
+    {
+        std::vector<uint32_t> handles(desc.n_objects);
+        std::iota(handles.begin(), handles.end(), 0u);
+        Builder b(ob, scene_tree);
+        scene_tree.root = b.build(handles, 0, handles.size());
+        if (b.nan_seen) { err = "NaN object centroid: partial_cmp().unwrap() panics (bvh.rs:99,109,119)"; return RTR_ERR_NAN_CENTROID; }
+    }
+
+    // ---- flatten: preorder nodes, leaves ranked in the reference's depth-first order ----
+    std::vector<uint32_t> obj_ref(desc.n_objects, REF_NONE);
+    std::vector<Box> obj_box(desc.n_objects);
+    std::vector<uint32_t> obj_height(desc.n_objects, 0);
+    Flattener fl{desc, meshes, scene_tree, out, obj_ref, obj_box, obj_height};
+    Flattener::Emitted root = fl.emit_scene_node(scene_tree.root);
+    out.root_ref = root.ref;
+    for (int k = 0; k < 3; k++) { out.root_box[k] = root.box.mn[k]; out.root_box[3 + k] = root.box.mx[k]; }
+    out.tree_height = root.height;
+    if (out.leaf_hot.size() > REF_INDEX || out.nodes.size() > REF_INDEX) { err = "scene too large"; return RTR_ERR_INVALID_ARGUMENT; }
+
+    // ---- the linear world's views (scene.rs:141-157): objects in Scene.objects order ----
+    out.n_objects = desc.n_objects; out.n_spheres = desc.n_spheres; out.n_meshes = desc.n_meshes;
+    out.objects.resize(desc.n_objects);
+    for (uint32_t i = 0; i < desc.n_objects; i++) {
+        DevObject &d = out.objects[i];
+        std::memset(&d, 0, sizeof d);
+        d.ref = obj_ref[i];
+        for (int k = 0; k < 3; k++) { d.box[k] = obj_box[i].mn[k]; d.box[3 + k] = obj_box[i].mx[k]; }
+        out.mesh_height = std::max(out.mesh_height, obj_height[i]);
+        if (desc.objects[i].kind == RTR_OBJ_MESH) out.n_triangles += desc.meshes[desc.objects[i].index].n_tris;
+    }
+    if (out.spheres_only) {
+        out.lin_spheres.resize(desc.n_objects);
+        for (uint32_t i = 0; i < desc.n_objects; i++) {
+            const rtr_sphere &s = desc.spheres[desc.objects[i].index];
+            DevLinSphere &d = out.lin_spheres[i];
+            std::memset(&d, 0, sizeof d);
+            d.center[0] = s.center[0]; d.center[1] = s.center[1]; d.center[2] = s.center[2];
+            d.radius = s.radius;
+            d.radius2 = s.radius * s.radius;
+            d.material = s.material;
+        }
+    }
+    return RTR_OK;
+}
+
+// Camera::ray_origin, lib/core/camera.rs:37-56 (cgmath operator order; tan on the host, as the reference)
+void camera_ray_origin(const rtr_camera &cam, float origin[3], float horizontal[3], float vertical[3], float llc[3]) {
+    const float pi = 3.14159265358979323846f;
+    float theta = cam.vertical_fov * pi / 180.0f; // degrees_to_radians, math.rs:31-33
+    float h = std::tan(theta / 2.0f);
+    float viewport_height = 2.0f * h;
+    float viewport_width = cam.aspect_ratio * viewport_height;
+    float w[3], u[3], v[3], t[3];
+    sub3(cam.lookfrom, cam.lookat, t);
+    float inv = 1.0f / std::sqrt((t[0] * t[0] + t[1] * t[1]) + t[2] * t[2]);
+    for (int k = 0; k < 3; k++) w[k] = t[k] * inv;
+    cross3(cam.vertical, w, t);
+    inv = 1.0f / std::sqrt((t[0] * t[0] + t[1] * t[1]) + t[2] * t[2]);
+    for (int k = 0; k < 3; k++) u[k] = t[k] * inv;
+    cross3(w, u, v);
+    for (int k = 0; k < 3; k++) {
+        origin[k] = cam.lookfrom[k];
+        horizontal[k] = viewport_width * u[k];
+        vertical[k] = viewport_height * v[k];
+        llc[k] = ((cam.lookfrom[k] - horizontal[k] / 2.0f) + vertical[k] / 2.0f) - w[k];
+    }
+}
+
+} // namespace rtr

@@ -1,0 +1,41 @@
+// rtr_scene.h -- host side of rtr_upload_scene: validate the POD scene, build the reference's two-level
+// median-split tree (lib/core/bvh.rs:59-144 over Scene, scene.rs:117-139, and over each Mesh,
+// mesh.rs:200-232) and flatten it into the arrays of rtr_device.h.  Pure C++ (no HIP): also used by
+// host-only contexts and the CPU test suite.
+#pragma once
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/rtr_hip.h"
+#include "rtr_device.h"
+
+namespace rtr {
+
+struct FlatScene {
+    std::vector<DevNode> nodes;
+    std::vector<DevLeafHot> leaf_hot;
+    std::vector<DevLeafCold> leaf_cold;
+    std::vector<DevLinSphere> lin_spheres;
+    std::vector<DevObject> objects;
+    std::vector<DevMaterial> materials;
+    std::vector<float> sky; // float4 texels
+    uint32_t sky_w = 0, sky_h = 0;
+    uint32_t bg_kind = 0;
+    float bg_a[3] = {0, 0, 0}, bg_b[3] = {0, 0, 0};
+    uint32_t root_ref = REF_NONE;
+    float root_box[6] = {0, 0, 0, 0, 0, 0};
+    uint32_t tree_height = 0;   // Split nodes on the longest root-to-leaf path of the scene tree
+    uint32_t mesh_height = 0;   // same, over the mesh subtrees alone (linear world with meshes)
+    bool spheres_only = true;
+    uint32_t n_objects = 0, n_spheres = 0, n_meshes = 0, n_triangles = 0;
+};
+
+// Returns RTR_OK or a negative rtr_status; on failure `err` holds the message.
+int build_flat_scene(const rtr_scene_desc &desc, FlatScene &out, std::string &err);
+
+// RayOrigin of Camera::ray_origin (lib/core/camera.rs:37-56): origin, horizontal, vertical, lower_left_corner
+void camera_ray_origin(const rtr_camera &cam, float origin[3], float horizontal[3], float vertical[3], float llc[3]);
+
+} // namespace rtr

@@ -1,0 +1,168 @@
+"""`render(target, scene)` -- the reference's entry point (lib/core/render.rs:61) over the HIP C ABI.
+
+    RenderTarget      lib/core/render.rs:14-30  (width, height, RGBA8 `data`, request_redraw)
+    render            lib/core/render.rs:61-127
+    Renderer          the amortised form: one context + one uploaded scene, many frames
+
+Everything numerical happens in librtr_hip.so; this module marshals arguments and owns buffers.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import numpy as np
+
+from . import _capi
+from .scene import LoweredScene, Scene, camera_struct, settings_struct
+
+DEFAULT_SEED = 0x5EED5EED5EED5EED
+
+
+class RenderTarget:
+    """lib/core/render.rs:14-30"""
+
+    def __init__(self, width: int, height: int):
+        self.width = int(width)
+        self.height = int(height)
+        self.data = np.zeros(self.width * self.height * 4, dtype=np.uint8)
+        self.request_redraw = False
+
+    def image(self) -> np.ndarray:
+        return self.data.reshape(self.height, self.width, 4)
+
+
+class SceneInfo:
+    def __init__(self, s: _capi.rtr_scene_info):
+        for name, _ in s._fields_:
+            setattr(self, name, int(getattr(s, name)))
+
+
+class Stats:
+    def __init__(self, s: _capi.rtr_stats):
+        for name, _ in s._fields_:
+            setattr(self, name, getattr(s, name))
+
+
+class Renderer:
+    """One rtr_context bound to one GPU (device >= 0) or host-only (device = -1: scene lowering + BVH
+    introspection only; rendering raises RTR_ERR_NO_DEVICE -- there is no CPU fallback)."""
+
+    def __init__(self, device: int = 0):
+        self._lib = _capi.load()
+        self._ctx = C.c_void_p()
+        rc = self._lib.rtr_create(int(device), C.byref(self._ctx))
+        if rc != _capi.RTR_OK:
+            raise _capi.RtrError(rc, (self._lib.rtr_last_error(None) or b"").decode())
+        self.device = device
+        self._scene: Optional[Scene] = None
+
+    def close(self) -> None:
+        if getattr(self, "_ctx", None) is not None and self._ctx:
+            self._lib.rtr_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _check(self, rc: int) -> None:
+        if rc != _capi.RTR_OK:
+            raise _capi.RtrError(rc, (self._lib.rtr_last_error(self._ctx) or b"").decode())
+
+    # -- scene -------------------------------------------------------------------------------------------
+    def upload_scene(self, scene: Scene) -> None:
+        lowered = LoweredScene(scene)
+        self._check(self._lib.rtr_upload_scene(self._ctx, C.byref(lowered.desc)))
+        self._scene = scene
+
+    def scene_info(self) -> SceneInfo:
+        s = _capi.rtr_scene_info()
+        self._check(self._lib.rtr_scene_info_get(self._ctx, C.byref(s)))
+        return SceneInfo(s)
+
+    def bvh_leaf_order(self) -> np.ndarray:
+        """(object index, triangle handle) of every leaf in the reference's depth-first order."""
+        n = self._lib.rtr_bvh_leaf_order(self._ctx, None, 0)
+        if n < 0:
+            self._check(int(n))
+        out = np.zeros(max(int(n), 1), dtype=np.uint64)
+        self._lib.rtr_bvh_leaf_order(self._ctx, out.ctypes.data_as(C.POINTER(C.c_uint64)), int(n))
+        out = out[: int(n)]
+        return np.stack([(out >> np.uint64(32)).astype(np.uint32), (out & np.uint64(0xFFFFFFFF)).astype(np.uint32)], axis=1)
+
+    # -- frames ------------------------------------------------------------------------------------------
+    def _cam_settings(self, scene: Optional[Scene]):
+        sc = scene if scene is not None else self._scene
+        if sc is None:
+            raise _capi.RtrError(-7, "no scene uploaded")
+        return camera_struct(sc.camera), settings_struct(sc.settings)
+
+    def render(self, width: int, height: int, seed: int = DEFAULT_SEED, want_rgba8: bool = True,
+               want_mean: bool = False, scene: Optional[Scene] = None) -> Tuple[Optional[np.ndarray], Optional[np.ndarray]]:
+        """One frame with host outputs: (rgba8[h,w,4] | None, mean_rgb[h,w,3] | None).  `scene` overrides the
+        camera/settings of the uploaded scene (its objects are NOT re-uploaded)."""
+        cam, st = self._cam_settings(scene)
+        rgba = np.zeros((height, width, 4), dtype=np.uint8) if want_rgba8 else None
+        mean = np.zeros((height, width, 3), dtype=np.float32) if want_mean else None
+        self._check(self._lib.rtr_render(
+            self._ctx, C.byref(cam), C.byref(st), width, height, C.c_uint64(seed),
+            rgba.ctypes.data_as(C.c_void_p) if rgba is not None else None,
+            mean.ctypes.data_as(C.c_void_p) if mean is not None else None))
+        return rgba, mean
+
+    def render_frame_device(self, width: int, height: int, seed: int, d_rgba8_ptr: int, stream: int = 0,
+                            scene: Optional[Scene] = None) -> None:
+        cam, st = self._cam_settings(scene)
+        self._check(self._lib.rtr_render_frame_device(self._ctx, C.byref(cam), C.byref(st), width, height,
+                                                      C.c_uint64(seed), C.c_void_p(d_rgba8_ptr), C.c_void_p(stream)))
+
+    def render_tiles_device(self, width: int, height: int, seed: int, shard: int, n_shards: int, d_sum_ptr: int,
+                            stream: int = 0, scene: Optional[Scene] = None) -> None:
+        cam, st = self._cam_settings(scene)
+        self._check(self._lib.rtr_render_tiles_device(self._ctx, C.byref(cam), C.byref(st), width, height,
+                                                      C.c_uint64(seed), shard, n_shards, C.c_void_p(d_sum_ptr),
+                                                      C.c_void_p(stream)))
+
+    def resolve_device(self, d_sum_ptr: int, spp: int, width: int, height: int, d_rgba8_ptr: int = 0,
+                       d_mean_ptr: int = 0, stream: int = 0) -> None:
+        self._check(self._lib.rtr_resolve_device(self._ctx, C.c_void_p(d_sum_ptr), spp, width, height,
+                                                 C.c_void_p(d_rgba8_ptr), C.c_void_p(d_mean_ptr), C.c_void_p(stream)))
+
+    def stats(self) -> Stats:
+        s = _capi.rtr_stats()
+        self._check(self._lib.rtr_get_stats(self._ctx, C.byref(s)))
+        return Stats(s)
+
+    def kernel_times_ms(self, cap: int = 64) -> np.ndarray:
+        out = np.zeros(cap, dtype=np.float32)
+        n = self._lib.rtr_kernel_times_ms(self._ctx, out.ctypes.data_as(C.POINTER(C.c_float)), cap)
+        if n < 0:
+            self._check(n)
+        return out[:n]
+
+    def segment_counts(self, cap: int = 64) -> np.ndarray:
+        out = np.zeros(cap, dtype=np.uint64)
+        n = self._lib.rtr_segment_counts(self._ctx, out.ctypes.data_as(C.POINTER(C.c_uint64)), cap)
+        if n < 0:
+            self._check(n)
+        return out[:n]
+
+
+def render(target: RenderTarget, scene: Scene, seed: int = DEFAULT_SEED, device: int = 0) -> None:
+    """lib/core/render.rs:61: fills `target.data` (RGBA8, row-major, y = 0 on top) and sets request_redraw.
+    Like the reference, the scene's acceleration structure is rebuilt on every call (render.rs:67); use a
+    `Renderer` to amortise the upload over many frames."""
+    target.request_redraw = True
+    with Renderer(device) as r:
+        r.upload_scene(scene)
+        rgba, _ = r.render(target.width, target.height, seed=seed, want_rgba8=True)
+    target.data[:] = rgba.reshape(-1)
