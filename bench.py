@@ -41,7 +41,8 @@ def parse_args():
     ap.add_argument("--scene", default=os.path.join(ROOT, "data", "scenes", "benchmark.json"))
     ap.add_argument("--bvh", action="store_true", help="render with enable_bvh_tree=true (not the headline)")
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=0x5EED5EED5EED5EED)
-    ap.add_argument("--cpu-spp", type=int, default=24, help="spp of the bounded CPU-baseline sample")
+    ap.add_argument("--cpu-spp", type=int, default=0,
+                    help="spp of the bounded CPU-baseline sample (0 = size it for ~15 s of CPU work)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pmc-traffic", type=float, default=None,
                     help="HBM bytes per launch from a separate rocprofv3 --pmc pass (profiles/), if collected")
@@ -57,8 +58,13 @@ def cpu_baseline(scene, width, height, spp_sample, seed):
 
     sc = copy.copy(scene)
     sc.settings = copy.copy(scene.settings)
-    sc.settings.samples_per_pixel = spp_sample
     cores = len(os.sched_getaffinity(0))
+    if spp_sample <= 0:
+        # size the sample for roughly 15 s of CPU work: probe at 2 spp, then scale (never above the real spp)
+        sc.settings.samples_per_pixel = 2
+        _, _, pr = pyoracle.OracleScene(sc).render(width, height, seed, threads=cores, want_rgba8=True, want_mean=False)
+        spp_sample = int(max(2, min(scene.settings.samples_per_pixel, round(15.0 / max(pr.seconds / 2.0, 1e-6)))))
+    sc.settings.samples_per_pixel = spp_sample
     _, _, st = pyoracle.OracleScene(sc).render(width, height, seed, threads=cores, want_rgba8=True, want_mean=False)
     return {
         "value": round(st.segments / st.seconds / 1e6, 3), "unit": "Mrays/s", "cores": int(st.threads), "kind": "port",
@@ -75,6 +81,7 @@ def main():
     import torch.distributed as dist
 
     import raytracingrust_amd as rt
+    from raytracingrust_amd.distributed import render_frame_distributed
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -109,11 +116,8 @@ def main():
         if not distributed:
             r.render_frame_device(W, H, seed, rgba8.data_ptr(), stream)
         else:
-            accum.zero_()
-            r.render_tiles_device(W, H, seed, rank, world, accum.data_ptr(), stream)
-            dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)
-            if rank == 0:
-                r.resolve_device(accum.data_ptr(), args.spp, W, H, rgba8.data_ptr(), 0, stream)
+            # zero -> integrate own tiles -> RCCL reduce(SUM) to rank 0 -> resolve on rank 0
+            render_frame_distributed(r, W, H, seed, accum, rgba8 if rank == 0 else None, stream=stream, spp=args.spp)
 
     def fence():
         torch.cuda.synchronize()

@@ -1,0 +1,60 @@
+"""Multi-GPU frames: one process per GPU (torch.distributed, backend "nccl" = RCCL over xGMI).
+
+The frame is cut into 8x8-pixel tiles (one 64-lane wave each, row-major tile index t); rank r of N owns the
+tiles with t % N == r -- interleaving balances sky-heavy and geometry-heavy regions.  Every
+rank integrates its tiles into a zeroed full-frame float4 sum buffer, one `reduce(SUM)` puts the frame on
+rank 0 (x + 0 = x, so the reduced frame is bit-identical to the single-GPU sums), and rank 0 resolves
+(mean, sqrt gamma, RGBA8: render.rs:103-110).  The random streams are keyed by (seed, pixel, sample), never
+by rank, so the image does not depend on N.
+
+Reference for the decomposition it replaces: the per-pixel rayon loop, lib/core/render.rs:114-119.
+"""
+from __future__ import annotations
+
+from typing import Callable, Optional
+
+import numpy as np
+
+TILE = 8
+
+
+def tile_grid(width: int, height: int):
+    return (width + TILE - 1) // TILE, (height + TILE - 1) // TILE
+
+
+def owned_pixel_mask(width: int, height: int, shard: int, n_shards: int) -> np.ndarray:
+    """Boolean [height, width] mask of the pixels rank `shard` integrates (the kernel's mapping:
+    tile = blockIdx.x * n_shards + shard, csrc/rtr_kernels.hip)."""
+    if not (0 <= shard < n_shards):
+        raise ValueError("shard must be in [0, n_shards)")
+    tx, ty = tile_grid(width, height)
+    tiles = np.arange(tx * ty, dtype=np.int64).reshape(ty, tx)
+    owned = (tiles % n_shards) == shard
+    return np.repeat(np.repeat(owned, TILE, axis=0), TILE, axis=1)[:height, :width]
+
+
+def render_frame_distributed(renderer, width: int, height: int, seed: int, accum, rgba8=None, stream: int = 0,
+                             group=None, integrate: Optional[Callable] = None, spp: Optional[int] = None,
+                             resolve: Optional[Callable] = None):
+    """One frame across the ranks of `group`.  `accum`: this rank's [H, W, 4] float32 tensor (device memory
+    for the HIP path); `rgba8`: rank 0's [H, W, 4] uint8 output.  `integrate` / `resolve` default to the HIP
+    entry points of `renderer`; the CPU (gloo) tests substitute stand-ins to exercise the sharding and the
+    collective without a GPU."""
+    import torch.distributed as dist
+
+    rank = dist.get_rank(group)
+    world = dist.get_world_size(group)
+    accum.zero_()
+    if integrate is None:
+        renderer.render_tiles_device(width, height, seed, rank, world, accum.data_ptr(), stream)
+    else:
+        integrate(width, height, seed, rank, world, accum)
+    dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM, group=group)
+    if rank == 0 and rgba8 is not None:
+        if spp is None:
+            spp = renderer._scene.settings.samples_per_pixel
+        if resolve is None:
+            renderer.resolve_device(accum.data_ptr(), spp, width, height, rgba8.data_ptr(), 0, stream)
+        else:
+            resolve(accum, spp, rgba8)
+    return accum
