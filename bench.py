@@ -88,12 +88,15 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    distributed = world > 1
+    # RTR_BENCH_FORCE_DISTRIBUTED=1 (testing aid): take the sharded + RCCL-reduce path even with one rank
+    distributed = world > 1 or os.environ.get("RTR_BENCH_FORCE_DISTRIBUTED") == "1"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(backend="nccl", device_id=dev, rank=rank, world_size=world)
 
     scene = rt.Scene.from_file(args.scene)
     scene.settings.samples_per_pixel = args.spp

@@ -109,7 +109,8 @@ class RtrError(RuntimeError):
 
 
 def library_path() -> str:
-    return _build.LIB_PATH
+    # RTR_HIP_LIBRARY: point at another build of the SAME library (kernel experiments); never a fallback
+    return os.environ.get("RTR_HIP_LIBRARY") or _build.LIB_PATH
 
 
 def load():

@@ -41,6 +41,20 @@ def needs_build() -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def build_variant(name: str, defines, verbose: bool = False) -> str:
+    """Kernel experiments: the same sources with extra -D flags, written next to the product library."""
+    out = os.path.join(LIB_DIR, f"librtr_hip_{name}.so")
+    os.makedirs(LIB_DIR, exist_ok=True)
+    cmd = [_hipcc()] + FLAGS + [d if d.startswith("-") else f"-D{d}" for d in defines] + ["-o", out] + [os.path.join(CSRC, s) for s in SOURCES]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        sys.stderr.write(r.stdout + r.stderr)
+        raise RuntimeError("hipcc failed")
+    return out
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not needs_build():
         return LIB_PATH
@@ -58,4 +72,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    if len(sys.argv) >= 3 and sys.argv[1] == "--variant":
+        print(build_variant(sys.argv[2], sys.argv[3:], verbose=True))
+    else:
+        print(build(force="--force" in sys.argv, verbose=True))

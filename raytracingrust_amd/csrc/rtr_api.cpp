@@ -20,7 +20,7 @@ namespace rtr {
 hipError_t launch_render(const RenderParams &p, uint32_t grid, uint32_t lds_bytes, hipStream_t stream);
 hipError_t launch_resolve(const float *sum_rgba, uint32_t spp, uint32_t n_pixels, uint8_t *rgba8, float *mean_rgb,
                           hipStream_t stream);
-hipError_t render_kernel_attributes(uint32_t world, int *vgprs, int *static_lds);
+hipError_t render_kernel_attributes(const RenderParams &p, int *vgprs, int *static_lds);
 } // namespace rtr
 
 namespace {
@@ -152,8 +152,11 @@ int launch_frame(rtr_context *ctx, const rtr_camera *camera, const rtr_settings 
     p.error_flag = ctx->d_error_flag;
 
     uint32_t grid = p.tiles_total > shard ? (p.tiles_total - shard + n_shards - 1u) / n_shards : 0u;
-    // dynamic LDS per wave: attenuation chain + traversal stack (refs + entry distances)
-    uint32_t lds_bytes = (p.max_depth + 2u * p.stack_cap) * 64u * 4u;
+    // small tables staged in LDS: the linear sphere world's records, and the materials when they fit 4 KB
+    p.sphere_regs = (p.world == rtr::WORLD_LINEAR_SPHERES && fs.n_objects >= 1u && fs.n_objects <= 8u) ? fs.n_objects : 0u;
+    p.lds_materials = (p.n_materials > 0u && p.n_materials <= 128u) ? p.n_materials : 0u;
+    // dynamic LDS per wave: attenuation chain + traversal stack (refs + entry distances) + the tables
+    uint32_t lds_bytes = (p.max_depth + 2u * p.stack_cap) * 64u * 4u + (p.sphere_regs + p.lds_materials) * 32u;
     if (lds_bytes > 160u * 1024u) return fail(ctx, RTR_ERR_UNSUPPORTED, "max_ray_depth + tree height exceed one CU's LDS");
     ctx->last_lds = lds_bytes;
     ctx->last_primary = 0;
@@ -175,7 +178,7 @@ int launch_frame(rtr_context *ctx, const rtr_camera *camera, const rtr_settings 
     ctx->launches++;
     {
         int vg = 0, sl = 0;
-        if (rtr::render_kernel_attributes(p.world, &vg, &sl) == hipSuccess) ctx->last_vgprs = (uint32_t)vg;
+        if (rtr::render_kernel_attributes(p, &vg, &sl) == hipSuccess) ctx->last_vgprs = (uint32_t)vg;
     }
     return RTR_OK;
 }

@@ -86,6 +86,8 @@ struct RenderParams {
     uint32_t root_ref;
     float root_box[6];
     uint32_t stack_cap; // entries per lane
+    uint32_t sphere_regs;   // linear sphere world: spheres held in scalar registers (0 = generic loop)
+    uint32_t lds_materials; // number of material records staged in LDS (0 = read from HBM/L1)
     const DevNode *nodes;
     const DevLeafHot *leaf_hot;
     const DevLeafCold *leaf_cold;

@@ -57,11 +57,14 @@ RTR_DEV uint32_t rng_u32(Rng &r) {
     uint32_t word = ((old >> ((old >> 28) + 4u)) ^ old) * 277803737u;
     return (word >> 22) ^ word;
 }
-// rand 0.8 float conversion: top 23 bits -> k*2^-23
-RTR_DEV float rng_value01(Rng &r) { return (float)(rng_u32(r) >> 9) * 0x1p-23f; }
+// rand 0.8 float conversions (top 23 bits k of a u32).  The reference forms k*2^-23 with an int->float
+// convert and scales it; here the same VALUES are assembled in the mantissa: (1.m) - 1 = k*2^-23 and
+// (2 + k*2^-22) - 3 = k*2^-22 - 1 are exact in f32, so the results are bit-identical to
+// value0_1*scale + low (the oracle computes them that way) at half the instructions.
+RTR_DEV float rng_value01(Rng &r) { return __uint_as_float(0x3f800000u | (rng_u32(r) >> 9)) - 1.0f; }
 RTR_DEV float rng_unit_inclusive(Rng &r) { return rng_value01(r) * 0x1.000002p+0f; } // Uniform::from(0.0..=1.0), render.rs:81
 RTR_DEV float rng_unit(Rng &r) { return rng_value01(r); }                            // gen_range(0.0..1.0), materials.rs:127,151
-RTR_DEV float rng_signed(Rng &r) { return rng_value01(r) * 2.0f + -1.0f; }           // gen_range(-1.0..1.0), sample.rs:29-31
+RTR_DEV float rng_signed(Rng &r) { return __uint_as_float(0x40000000u | (rng_u32(r) >> 9)) - 3.0f; } // gen_range(-1.0..1.0), sample.rs:29-31
 
 // sample.rs:43-51 rejection-sampled unit ball; returns |v|^2 through m2
 RTR_DEV V3 sample_unit_ball(Rng &rng, float &m2) {
@@ -71,6 +74,9 @@ RTR_DEV V3 sample_unit_ball(Rng &rng, float &m2) {
         v.y = rng_signed(rng);
         v.z = rng_signed(rng);
         m2 = dot(v, v);
+#ifdef RTR_X_NOREJECT // timing experiment only (never defined in the product build): accept the first candidate
+        break;
+#endif
     } while (!(m2 <= 1.0f));
     return v;
 }
@@ -331,11 +337,43 @@ RTR_DEV void finish_leaf(const RenderParams &p, const Best &best, const Ray &r, 
     }
 }
 
+// Linear world of NS <= 8 spheres: centre and r^2 of every sphere live in scalar registers for the whole
+// kernel (loaded once, wave-uniform); the winner's radius / material come from a 32-B-per-sphere LDS table.
+template <uint32_t NS>
+struct SphereRegs {
+    float cx[NS ? NS : 1], cy[NS ? NS : 1], cz[NS ? NS : 1], r2[NS ? NS : 1];
+};
+
 // world.hit (render.rs:38).  Returns false on miss.
-template <uint32_t WORLD>
-RTR_DEV bool world_hit(const RenderParams &p, const Ray &r, Hit &h, uint32_t *stk_ref, float *stk_t, uint32_t lane) {
+template <uint32_t WORLD, uint32_t NS>
+RTR_DEV bool world_hit(const RenderParams &p, const Ray &r, Hit &h, uint32_t *stk_ref, float *stk_t, uint32_t lane,
+                       const SphereRegs<NS> &sr, const uint32_t *lds_spheres) {
     const float a = dot(r.d, r.d); // objects.rs:25, hoisted per ray
-    if constexpr (WORLD == WORLD_LINEAR_SPHERES) {
+    if constexpr (WORLD == WORLD_LINEAR_SPHERES && NS > 0) {
+        // scene.rs:141-157, fully unrolled
+        float closest = __builtin_inff();
+        int best = -1;
+#ifdef RTR_X_ONESPHERE // timing experiment only: test the last sphere alone
+#define RTR_X_FIRST (NS - 1)
+#else
+#define RTR_X_FIRST 0
+#endif
+#pragma unroll
+        for (uint32_t i = RTR_X_FIRST; i < NS; i++) {
+            float t;
+            if (sphere_t(mk(sr.cx[i], sr.cy[i], sr.cz[i]), sr.r2[i], r, a, closest, t)) {
+                closest = t;
+                best = (int)i;
+            }
+        }
+        if (best < 0) return false;
+        const float4 w = *reinterpret_cast<const float4 *>(lds_spheres + best * 8); // centre, radius
+        h.material = lds_spheres[best * 8 + 5];
+        h.point = add(r.o, scale(r.d, closest));
+        V3 outward = divs(sub(h.point, mk(w.x, w.y, w.z)), w.w);
+        face_forward(h, r, outward);
+        return true;
+    } else if constexpr (WORLD == WORLD_LINEAR_SPHERES) {
         // scene.rs:141-157: ordered scan, closest_so_far shrinks, later object wins exact ties
         float closest = __builtin_inff();
         int best = -1;
@@ -425,10 +463,21 @@ RTR_DEV float reflectance(float cosine, float idx) { // materials.rs:103-108; po
     return r0 + (1.0f - r0) * (x * x4);
 }
 
-RTR_DEV V3 material_rgb(const RenderParams &p, uint32_t id) {
+// Material records: from the LDS copy when the kernel staged one (lds_mats != nullptr), else from HBM/L1.
+RTR_DEV void material_load(const RenderParams &p, const uint32_t *lds_mats, uint32_t id, float4 &q0, float4 &q1) {
+    if (lds_mats) {
+        const float4 *m = reinterpret_cast<const float4 *>(lds_mats + id * 8u);
+        q0 = m[0]; q1 = m[1];
+    } else {
+        const float4 *m = reinterpret_cast<const float4 *>(p.materials + id);
+        q0 = m[0]; q1 = m[1];
+    }
+}
+RTR_DEV V3 material_rgb(const RenderParams &p, const uint32_t *lds_mats, uint32_t id) {
     if (id == kChainClay) return mk(0.8f, 0.8f, 0.8f);
-    const float4 *m = reinterpret_cast<const float4 *>(p.materials + id);
-    float4 q = m[0];
+    float4 q;
+    if (lds_mats) q = *reinterpret_cast<const float4 *>(lds_mats + id * 8u);
+    else q = *reinterpret_cast<const float4 *>(p.materials + id);
     return mk(q.x, q.y, q.z);
 }
 
@@ -451,16 +500,45 @@ RTR_DEV V3 background(const RenderParams &p, const Ray &r) {
     return mk(texel.x, texel.y, texel.z);
 }
 
-// One wave = one 8x8 tile.  LDS (dynamic): [chain: max_depth x 64 u32][stack refs: cap x 64][stack t: cap x 64]
-template <uint32_t WORLD>
-__global__ __launch_bounds__(64) void k_render(const RenderParams p) {
-    extern __shared__ uint32_t lds[];
+// One wave = one 8x8 tile.  LDS (dynamic, 16-byte aligned pieces):
+//   [chain: max_depth x 64 u32][stack refs: cap x 64][stack t: cap x 64][spheres: NS x 8][materials: lds_mats x 8]
+#ifndef RTR_X_WAVES_PER_EU
+#define RTR_X_WAVES_PER_EU 1
+#endif
+template <uint32_t WORLD, uint32_t NS>
+__global__ __launch_bounds__(64, RTR_X_WAVES_PER_EU) void k_render(const RenderParams p) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const uint32_t lane = threadIdx.x;
+#if defined(RTR_X_STRIDE) // timing experiment: scatter concurrently running tiles over the image
+    if (blockIdx.x * p.n_shards + p.shard >= p.tiles_total) return;
+    const uint32_t tile = (uint32_t)(((unsigned long long)(blockIdx.x * p.n_shards + p.shard) * RTR_X_STRIDE) % p.tiles_total);
+#elif defined(RTR_X_REVERSE) // timing experiment: bottom rows (geometry-heavy) first, sky tiles last
+    const uint32_t tile = p.tiles_total - 1u - (blockIdx.x * p.n_shards + p.shard);
+    if (tile >= p.tiles_total) return;
+#else
     const uint32_t tile = blockIdx.x * p.n_shards + p.shard;
     if (tile >= p.tiles_total) return;
+#endif
     uint32_t *chain = lds;
     uint32_t *stk_ref = lds + p.max_depth * 64u;
     float *stk_t = reinterpret_cast<float *>(stk_ref + p.stack_cap * 64u);
+    uint32_t *lds_spheres = reinterpret_cast<uint32_t *>(stk_t + p.stack_cap * 64u);
+    uint32_t *lds_mat_base = lds_spheres + NS * 8u;
+    const uint32_t *lds_mats = p.lds_materials ? lds_mat_base : nullptr;
+    // stage the small tables (one wave per workgroup: no barrier needed beyond the LDS wait)
+    SphereRegs<NS> sr;
+    if constexpr (NS > 0) {
+#pragma unroll
+        for (uint32_t i = 0; i < NS; i++) {
+            const DevLinSphere &sp = p.lin_spheres[i]; // uniform -> scalar loads, kept in SGPRs
+            sr.cx[i] = sp.center[0]; sr.cy[i] = sp.center[1]; sr.cz[i] = sp.center[2]; sr.r2[i] = sp.radius2;
+        }
+        for (uint32_t i = lane; i < NS * 8u; i += 64u) lds_spheres[i] = reinterpret_cast<const uint32_t *>(p.lin_spheres)[i];
+    }
+    if (p.lds_materials)
+        for (uint32_t i = lane; i < p.lds_materials * 8u; i += 64u) lds_mat_base[i] = reinterpret_cast<const uint32_t *>(p.materials)[i];
+    __builtin_amdgcn_s_waitcnt(0); // vmcnt(0) lgkmcnt(0): the tables are in LDS before any lane reads them
+    __builtin_amdgcn_wave_barrier();
 
     const uint32_t tx = tile % p.tiles_x, ty = tile / p.tiles_x;
     const uint32_t x = tx * 8u + (lane & 7u), y = ty * 8u + (lane >> 3);
@@ -495,13 +573,19 @@ __global__ __launch_bounds__(64) void k_render(const RenderParams p) {
     };
     if (spp > 0u) start_sample(0u);
 
+#ifdef RTR_X_COUNT_ITERS // diagnostic build only: the segment counter returns wave-iterations*64 instead
+    uint32_t n_iter = 0;
+#endif
     while (s < spp) {
         // ---- trace_ray body (render.rs:32-59): one segment ----
         Hit h;
         nseg++;
+#ifdef RTR_X_COUNT_ITERS
+        n_iter++;
+#endif
         bool done;
         V3 term;
-        if (!world_hit<WORLD>(p, ray, h, stk_ref, stk_t, lane)) {
+        if (!world_hit<WORLD, NS>(p, ray, h, stk_ref, stk_t, lane, sr, lds_spheres)) {
             term = background(p, ray);
             done = true;
         } else if (p.mode == 3u) { // RenderMode::Normal, render.rs:42-45
@@ -520,8 +604,8 @@ __global__ __launch_bounds__(64) void k_render(const RenderParams p) {
             } else {
                 // MixMaterial::scatter (materials.rs:148-157): xi >= factor -> first
                 for (;;) {
-                    const float4 *m = reinterpret_cast<const float4 *>(p.materials + mid);
-                    float4 q0 = m[0], q1 = m[1];
+                    float4 q0, q1;
+                    material_load(p, lds_mats, mid, q0, q1);
                     kind = __float_as_uint(q1.x);
                     rgb = mk(q0.x, q0.y, q0.z);
                     param = q0.w;
@@ -531,12 +615,21 @@ __global__ __launch_bounds__(64) void k_render(const RenderParams p) {
             }
             bool scattered = true;
             V3 ndir = h.normal;
+            // Lambertian, Metal and Isotropic all start from one rejection-sampled point of the unit ball
+            // (sample.rs:43-51) and it is their first draw after the mix walk, so the loop is run ONCE for all
+            // three kinds (one divergent loop per segment instead of one per material kind).
+            V3 sv = mk(0.0f, 0.0f, 0.0f);
+            if (kind == 0u || kind == 1u || kind == 5u) {
+                float m2;
+                sv = sample_unit_ball(rng, m2);
+                if (kind != 5u) sv = scale(sv, 1.0f / sqrtf(m2)); // sample_unit_sphere_surface, sample.rs:66-70
+            }
             if (kind == 0u) { // Lambertian, materials.rs:31-41
-                ndir = add(h.normal, sample_unit_sphere(rng));
+                ndir = add(h.normal, sv);
                 if (near_zero(ndir)) ndir = h.normal;
             } else if (kind == 1u) { // Metal, materials.rs:58-70
                 V3 reflected = normalize(reflect(ray.d, h.normal));
-                ndir = add(reflected, scale(sample_unit_sphere(rng), param));
+                ndir = add(reflected, scale(sv, param));
                 if (!(dot(ndir, h.normal) > 0.0f)) { scattered = false; term = mk(0.0f, 0.0f, 0.0f); }
             } else if (kind == 2u) { // Emission, materials.rs:86-91
                 scattered = false; term = rgb;
@@ -550,9 +643,8 @@ __global__ __launch_bounds__(64) void k_render(const RenderParams p) {
                 if (!refl) refl = reflectance(cos_theta, ratio) > rng_unit(rng); // no draw on TIR (short-circuit ||)
                 ndir = refl ? reflect(unit, h.normal) : refract(unit, h.normal, ratio);
                 mid = 0xFFFFFFFEu; // attenuation (1,1,1): x*1 == x exactly, nothing to replay
-            } else { // Isotropic, volume.rs:80-88
-                float m2;
-                ndir = sample_unit_ball(rng, m2);
+            } else { // Isotropic, volume.rs:80-88: the un-normalised ball sample is the direction
+                ndir = sv;
             }
             if (scattered) {
                 if (mid != 0xFFFFFFFEu) { chain[nchain * 64u + lane] = mid; nchain++; }
@@ -569,7 +661,7 @@ __global__ __launch_bounds__(64) void k_render(const RenderParams p) {
             // attenuation * (attenuation * (... * terminal)), render.rs:52
             while (nchain > 0u) {
                 nchain--;
-                term = mul(material_rgb(p, chain[nchain * 64u + lane]), term);
+                term = mul(material_rgb(p, lds_mats, chain[nchain * 64u + lane]), term);
             }
             // f32::clamp(0, clamp_indirect), NaN stays NaN (render.rs:95-97)
             const float hi = p.clamp_indirect;
@@ -606,6 +698,13 @@ __global__ __launch_bounds__(64) void k_render(const RenderParams p) {
         }
     }
 
+#ifdef RTR_X_COUNT_ITERS
+    {
+        uint32_t m = n_iter;
+        for (int off = 32; off > 0; off >>= 1) { uint32_t o = __shfl_xor(m, off, 64); m = o > m ? o : m; }
+        nseg = m; // every lane reports the wave's trip count: the sum is trips*64
+    }
+#endif
     // one atomic per wave
     unsigned long long total = nseg;
     for (int off = 32; off > 0; off >>= 1) total += __shfl_xor(total, off, 64);
@@ -632,11 +731,28 @@ __global__ __launch_bounds__(256) void k_resolve(const float *sum_rgba, uint32_t
 }
 
 // --- launchers (called from rtr_api.cpp) -----------------------------------------------------------------
+template <uint32_t NS>
+static void launch_spheres(const RenderParams &p, uint32_t grid, uint32_t lds_bytes, hipStream_t stream) {
+    hipLaunchKernelGGL((k_render<WORLD_LINEAR_SPHERES, NS>), dim3(grid), dim3(64), lds_bytes, stream, p);
+}
+
 hipError_t launch_render(const RenderParams &p, uint32_t grid, uint32_t lds_bytes, hipStream_t stream) {
     switch (p.world) {
-    case WORLD_LINEAR_SPHERES: hipLaunchKernelGGL(k_render<WORLD_LINEAR_SPHERES>, dim3(grid), dim3(64), lds_bytes, stream, p); break;
-    case WORLD_BVH: hipLaunchKernelGGL(k_render<WORLD_BVH>, dim3(grid), dim3(64), lds_bytes, stream, p); break;
-    default: hipLaunchKernelGGL(k_render<WORLD_LINEAR_GENERIC>, dim3(grid), dim3(64), lds_bytes, stream, p); break;
+    case WORLD_LINEAR_SPHERES:
+        switch (p.sphere_regs) { // number of spheres held in scalar registers (0 = generic loop)
+        case 1: launch_spheres<1>(p, grid, lds_bytes, stream); break;
+        case 2: launch_spheres<2>(p, grid, lds_bytes, stream); break;
+        case 3: launch_spheres<3>(p, grid, lds_bytes, stream); break;
+        case 4: launch_spheres<4>(p, grid, lds_bytes, stream); break;
+        case 5: launch_spheres<5>(p, grid, lds_bytes, stream); break;
+        case 6: launch_spheres<6>(p, grid, lds_bytes, stream); break;
+        case 7: launch_spheres<7>(p, grid, lds_bytes, stream); break;
+        case 8: launch_spheres<8>(p, grid, lds_bytes, stream); break;
+        default: launch_spheres<0>(p, grid, lds_bytes, stream); break;
+        }
+        break;
+    case WORLD_BVH: hipLaunchKernelGGL((k_render<WORLD_BVH, 0>), dim3(grid), dim3(64), lds_bytes, stream, p); break;
+    default: hipLaunchKernelGGL((k_render<WORLD_LINEAR_GENERIC, 0>), dim3(grid), dim3(64), lds_bytes, stream, p); break;
     }
     return hipGetLastError();
 }
@@ -648,14 +764,25 @@ hipError_t launch_resolve(const float *sum_rgba, uint32_t spp, uint32_t n_pixels
     return hipGetLastError();
 }
 
-hipError_t render_kernel_attributes(uint32_t world, int *vgprs, int *static_lds) {
+hipError_t render_kernel_attributes(const RenderParams &p, int *vgprs, int *static_lds) {
     hipFuncAttributes attr;
-    hipError_t e;
-    switch (world) {
-    case WORLD_LINEAR_SPHERES: e = hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(k_render<WORLD_LINEAR_SPHERES>)); break;
-    case WORLD_BVH: e = hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(k_render<WORLD_BVH>)); break;
-    default: e = hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(k_render<WORLD_LINEAR_GENERIC>)); break;
+    const void *fn;
+    if (p.world == WORLD_BVH) fn = reinterpret_cast<const void *>(k_render<WORLD_BVH, 0>);
+    else if (p.world == WORLD_LINEAR_GENERIC) fn = reinterpret_cast<const void *>(k_render<WORLD_LINEAR_GENERIC, 0>);
+    else {
+        switch (p.sphere_regs) {
+        case 1: fn = reinterpret_cast<const void *>(k_render<WORLD_LINEAR_SPHERES, 1>); break;
+        case 2: fn = reinterpret_cast<const void *>(k_render<WORLD_LINEAR_SPHERES, 2>); break;
+        case 3: fn = reinterpret_cast<const void *>(k_render<WORLD_LINEAR_SPHERES, 3>); break;
+        case 4: fn = reinterpret_cast<const void *>(k_render<WORLD_LINEAR_SPHERES, 4>); break;
+        case 5: fn = reinterpret_cast<const void *>(k_render<WORLD_LINEAR_SPHERES, 5>); break;
+        case 6: fn = reinterpret_cast<const void *>(k_render<WORLD_LINEAR_SPHERES, 6>); break;
+        case 7: fn = reinterpret_cast<const void *>(k_render<WORLD_LINEAR_SPHERES, 7>); break;
+        case 8: fn = reinterpret_cast<const void *>(k_render<WORLD_LINEAR_SPHERES, 8>); break;
+        default: fn = reinterpret_cast<const void *>(k_render<WORLD_LINEAR_SPHERES, 0>); break;
+        }
     }
+    hipError_t e = hipFuncGetAttributes(&attr, fn);
     if (e == hipSuccess) { *vgprs = attr.numRegs; *static_lds = (int)attr.sharedSizeBytes; }
     return e;
 }

@@ -94,3 +94,70 @@ def test_house_scene(gpu_renderer):
     assert max(c["rel_l2"]) <= TOL, c
     assert c["max_u8_delta"] <= 1
     assert st.segments == o_st.segments
+
+
+@pytest.mark.parametrize("n_shards", [1, 2, 3, 8])
+def test_sharded_tiles_plus_resolve_equal_fused_frame(gpu_renderer, n_shards):
+    """The multi-GPU decomposition on one GPU: every shard renders its 8x8 tiles into its own zeroed float4
+    buffer, the buffers are summed (what the RCCL reduce does), rtr_resolve_device finishes the frame.  Must be
+    bit-identical to the fused single-kernel frame (x + 0 = x) and to the oracle."""
+    import torch
+
+    from raytracingrust_amd.distributed import owned_pixel_mask
+
+    w, h, seed = 100, 52, 99  # not multiples of 8: ragged edge tiles
+    scene = simple_scene(4)
+    r = gpu_renderer
+    r.upload_scene(scene)
+    rgba_f, mean_f = r.render(w, h, seed=seed, want_rgba8=True, want_mean=True)
+    seg_f = r.stats().segments
+    dev = torch.device("cuda", 0)
+    total = torch.zeros((h, w, 4), dtype=torch.float32, device=dev)
+    segs = 0
+    for shard in range(n_shards):
+        part = torch.zeros((h, w, 4), dtype=torch.float32, device=dev)
+        torch.cuda.synchronize()
+        r.render_tiles_device(w, h, seed, shard, n_shards, part.data_ptr(), 0)
+        st = r.stats()  # synchronises
+        segs += st.segments
+        mask = torch.from_numpy(owned_pixel_mask(w, h, shard, n_shards)).to(dev)
+        assert torch.all(part[~mask] == 0), "a shard must not touch pixels it does not own"
+        total += part
+    assert segs == seg_f
+    rgba = torch.zeros((h, w, 4), dtype=torch.uint8, device=dev)
+    mean = torch.zeros((h, w, 3), dtype=torch.float32, device=dev)
+    torch.cuda.synchronize()
+    r.resolve_device(total.data_ptr(), scene.settings.samples_per_pixel, w, h, rgba.data_ptr(), mean.data_ptr(), 0)
+    r.stats()
+    torch.cuda.synchronize()
+    assert np.array_equal(mean.cpu().numpy().view(np.uint32), mean_f.view(np.uint32))
+    assert np.array_equal(rgba.cpu().numpy(), rgba_f)
+    o_rgba, o_mean, _ = pyoracle.OracleScene(scene).render(w, h, seed, threads=0)
+    assert np.array_equal(o_mean.view(np.uint32), mean_f.view(np.uint32)) and np.array_equal(o_rgba, rgba_f)
+
+
+def test_render_entry_point_fills_render_target(gpu_renderer):
+    """rt.render(target, scene): the reference's signature (render.rs:61)."""
+    scene = benchmark_scene(4)
+    target = rt.RenderTarget(64, 40)
+    rt.render(target, scene, seed=5)
+    assert target.request_redraw
+    o_rgba, _, _ = pyoracle.OracleScene(scene).render(64, 40, 5, threads=0)
+    assert np.array_equal(target.image(), o_rgba)
+
+
+def test_full_size_frame_properties(gpu_renderer):
+    """BASELINE's full frame size (1920x1080) at low spp: size-independent properties -- determinism, seed
+    sensitivity, alpha = 255, sky pixels exactly the background, device-counted segments within the depth bound."""
+    scene = benchmark_scene(2)
+    r = gpu_renderer
+    r.upload_scene(scene)
+    a, _ = r.render(1920, 1080, seed=1)
+    seg = r.stats().segments
+    b, _ = r.render(1920, 1080, seed=1)
+    c, _ = r.render(1920, 1080, seed=2)
+    assert np.array_equal(a, b) and not np.array_equal(a, c)
+    assert np.all(a[..., 3] == 255)
+    assert np.all(a[:40, 600:1300, :3] == 197)  # sky: trunc(sqrt(0.6)*255)
+    n = 1920 * 1080 * 2
+    assert n <= seg <= n * scene.settings.max_ray_depth
