@@ -40,6 +40,9 @@ def parse_args():
     ap.add_argument("--spp", type=int, default=256)
     ap.add_argument("--scene", default=os.path.join(ROOT, "data", "scenes", "benchmark.json"))
     ap.add_argument("--bvh", action="store_true", help="render with enable_bvh_tree=true (not the headline)")
+    ap.add_argument("--config", default=None,
+                    help="another BASELINE configuration (c1,c2b,c3,c3l,c4,c5: raytracingrust_amd/configs.py) instead "
+                         "of the headline scene; width/height come from the configuration")
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=0x5EED5EED5EED5EED)
     ap.add_argument("--cpu-spp", type=int, default=0,
                     help="spp of the bounded CPU-baseline sample (0 = size it for ~15 s of CPU work)")
@@ -98,11 +101,17 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group(backend="nccl", device_id=dev, rank=rank, world_size=world)
 
-    scene = rt.Scene.from_file(args.scene)
-    scene.settings.samples_per_pixel = args.spp
-    if args.bvh:
-        scene.settings.enable_bvh_tree = True
-    W, H = args.width, args.height
+    if args.config:
+        from raytracingrust_amd.configs import baseline_config
+
+        scene, W, H = baseline_config(args.config, args.spp)
+        args.scene = args.config
+    else:
+        scene = rt.Scene.from_file(args.scene)
+        scene.settings.samples_per_pixel = args.spp
+        if args.bvh:
+            scene.settings.enable_bvh_tree = True
+        W, H = args.width, args.height
 
     r = rt.Renderer(local_rank)
     r.upload_scene(scene)

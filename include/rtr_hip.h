@@ -215,6 +215,9 @@ int rtr_get_stats(rtr_context *ctx, rtr_stats *out);
 /* HIP-event durations (ms) of the most recent render kernels, oldest first; returns how many were written
  * (at most cap, at most 64).  Waits for outstanding work. */
 int rtr_kernel_times_ms(rtr_context *ctx, float *out, uint32_t cap);
+/* Device self-test: the kernels' correctly-rounded square root (csrc/rtr_kernels.hip rt_sqrt) against the
+ * compiler's sqrtf() over all 2^32 f32 bit patterns; *mismatches must come back 0. */
+int rtr_selftest_sqrt(rtr_context *ctx, uint64_t *mismatches);
 /* Device-counted ray segments of the same launches, in the same order. */
 int rtr_segment_counts(rtr_context *ctx, uint64_t *out, uint32_t cap);
 

@@ -97,6 +97,7 @@ SYMBOLS = [
     ("rtr_get_stats", C.c_int, [_ctx, C.POINTER(rtr_stats)]),
     ("rtr_kernel_times_ms", C.c_int, [_ctx, C.POINTER(C.c_float), C.c_uint32]),
     ("rtr_segment_counts", C.c_int, [_ctx, C.POINTER(C.c_uint64), C.c_uint32]),
+    ("rtr_selftest_sqrt", C.c_int, [_ctx, C.POINTER(C.c_uint64)]),
 ]
 
 _lib = None

@@ -21,6 +21,7 @@ hipError_t launch_render(const RenderParams &p, uint32_t grid, uint32_t lds_byte
 hipError_t launch_resolve(const float *sum_rgba, uint32_t spp, uint32_t n_pixels, uint8_t *rgba8, float *mean_rgb,
                           hipStream_t stream);
 hipError_t render_kernel_attributes(const RenderParams &p, int *vgprs, int *static_lds);
+hipError_t launch_selftest_sqrt(unsigned long long *d_mismatches, hipStream_t stream);
 } // namespace rtr
 
 namespace {
@@ -424,6 +425,19 @@ int rtr_kernel_times_ms(rtr_context *ctx, float *out, uint32_t cap) {
         out[i] = ms;
     }
     return (int)n;
+}
+
+int rtr_selftest_sqrt(rtr_context *ctx, uint64_t *mismatches) {
+    if (!ctx || !mismatches) return RTR_ERR_INVALID_ARGUMENT;
+    if (ctx->device < 0) return fail(ctx, RTR_ERR_NO_DEVICE, "host-only context: no HIP device bound (there is no CPU fallback)");
+    RTR_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    RTR_HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, sizeof(unsigned long long), ctx->stream));
+    RTR_HIP_TRY(ctx, rtr::launch_selftest_sqrt(ctx->d_counters, ctx->stream));
+    unsigned long long bad = 0;
+    RTR_HIP_TRY(ctx, hipMemcpyAsync(&bad, ctx->d_counters, sizeof bad, hipMemcpyDeviceToHost, ctx->stream));
+    RTR_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    *mismatches = bad;
+    return RTR_OK;
 }
 
 int rtr_segment_counts(rtr_context *ctx, uint64_t *out, uint32_t cap) {

@@ -38,8 +38,26 @@ RTR_DEV float dot(V3 a, V3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
 RTR_DEV V3 cross(V3 a, V3 b) {
     return mk((a.y * b.z) - (a.z * b.y), (a.z * b.x) - (a.x * b.z), (a.x * b.y) - (a.y * b.x));
 }
+// Correctly rounded f32 square root.  hipcc's expansion of sqrtf() is v_sqrt_f32 (1 ulp) + a test of the
+// two neighbouring floats with exact fma residuals, wrapped in 2^32 input scaling for denormals and a class
+// check for 0/inf/NaN (20 instructions, 10 of them half-rate selects/compares).  For x in [2^-100, 2^100) the
+// wrapping is dead weight: this is the same neighbour test without it (9 instructions), sqrtf() otherwise.
+// rtr_selftest_sqrt() compares the two over all 2^32 bit patterns on the device (tests/test_gpu_selftest.py).
+RTR_DEV float rt_sqrt(float x) {
+    const uint32_t b = __float_as_uint(x);
+    if ((b - 0x0D800000u) < 0x65000000u) { // sign 0, biased exponent in [27, 228)
+        float s = __builtin_amdgcn_sqrtf(x);
+        const float lo = __uint_as_float(__float_as_uint(s) - 1u), hi = __uint_as_float(__float_as_uint(s) + 1u);
+        const float rl = __builtin_fmaf(-lo, s, x), rh = __builtin_fmaf(-hi, s, x);
+        if (rl <= 0.0f) s = lo;
+        if (rh > 0.0f) s = hi;
+        return s;
+    }
+    return sqrtf(x);
+}
+
 // cgmath normalize = v * (1/|v|)
-RTR_DEV V3 normalize(V3 a) { return scale(a, 1.0f / sqrtf(dot(a, a))); }
+RTR_DEV V3 normalize(V3 a) { return scale(a, 1.0f / rt_sqrt(dot(a, a))); }
 
 constexpr float kPi = 3.14159265358979323846f;
 constexpr float kTMin = 0.00001f; // render.rs:38
@@ -84,7 +102,7 @@ RTR_DEV V3 sample_unit_ball(Rng &rng, float &m2) {
 RTR_DEV V3 sample_unit_sphere(Rng &rng) {
     float m2;
     V3 v = sample_unit_ball(rng, m2);
-    return scale(v, 1.0f / sqrtf(m2));
+    return scale(v, 1.0f / rt_sqrt(m2));
 }
 
 // --- polynomial acos / atan2 for SkyMap (same sequence as the oracle's OR_TRIG_POLY) -----------------
@@ -172,9 +190,13 @@ RTR_DEV bool sphere_t(V3 c, float r2, const Ray &r, float a, float tmax, float &
     float cc = dot(oc, oc) - r2;
     float disc = half_b * half_b - a * cc;
     if (disc < 0.0f) return false;
-    float sq = sqrtf(disc);
+    float sq = rt_sqrt(disc);
     float root = (-half_b - sq) / a;
-    if (root < kTMin || tmax < root) {
+    // objects.rs:39-44: `if root < tmin || tmax < root { second root ... }`.  When the FIRST root is already
+    // beyond tmax the second (>= the first: sq >= 0, a >= 0) is too, so its division is skipped; a NaN root
+    // fails both comparisons and is accepted, exactly as in the reference.
+    if (tmax < root) return false;
+    if (root < kTMin) {
         root = (-half_b + sq) / a;
         if (root < kTMin || tmax < root) return false;
     }
@@ -324,7 +346,7 @@ RTR_DEV void finish_leaf(const RenderParams &p, const Best &best, const Ray &r, 
         V3 n = add(add(scale(n1, u), scale(n2, v)), scale(n0, 1.0f - u - v));
         // mesh.rs:187: normal.angle(face) > 0 with cgmath angle = atan2(|n x f|, n.f)
         V3 cr = cross(n, fn);
-        float mag = sqrtf(dot(cr, cr));
+        float mag = rt_sqrt(dot(cr, cr));
         float dd = dot(n, fn);
         bool use_face = (mag > 0.0f) || (mag == 0.0f && (dd < 0.0f || (dd == 0.0f && __builtin_signbit(dd))));
         if (use_face) n = fn;
@@ -350,16 +372,13 @@ RTR_DEV bool world_hit(const RenderParams &p, const Ray &r, Hit &h, uint32_t *st
                        const SphereRegs<NS> &sr, const uint32_t *lds_spheres) {
     const float a = dot(r.d, r.d); // objects.rs:25, hoisted per ray
     if constexpr (WORLD == WORLD_LINEAR_SPHERES && NS > 0) {
-        // scene.rs:141-157, fully unrolled
+        // scene.rs:141-157, fully unrolled over scalar-register sphere constants.  (A two-pass variant -- candidate
+        // bits from the discriminants, then a per-lane loop over candidates only -- was measured 1 % slower:
+        // +10 VGPRs and an LDS fetch per candidate outweigh the skipped root blocks.)
         float closest = __builtin_inff();
         int best = -1;
-#ifdef RTR_X_ONESPHERE // timing experiment only: test the last sphere alone
-#define RTR_X_FIRST (NS - 1)
-#else
-#define RTR_X_FIRST 0
-#endif
 #pragma unroll
-        for (uint32_t i = RTR_X_FIRST; i < NS; i++) {
+        for (uint32_t i = 0; i < NS; i++) {
             float t;
             if (sphere_t(mk(sr.cx[i], sr.cy[i], sr.cz[i]), sr.r2[i], r, a, closest, t)) {
                 closest = t;
@@ -451,7 +470,7 @@ RTR_DEV V3 reflect(V3 v, V3 n) { return sub(v, scale(n, 2.0f * dot(v, n))); } //
 RTR_DEV V3 refract(V3 uv, V3 n, float eta) {                                    // math.rs:16-21
     float cos_theta = fminf(dot(n, neg(uv)), 1.0f);
     V3 out_perp = scale(add(uv, scale(n, cos_theta)), eta);
-    V3 out_parallel = scale(n, -sqrtf(fabsf(1.0f - dot(out_perp, out_perp))));
+    V3 out_parallel = scale(n, -rt_sqrt(fabsf(1.0f - dot(out_perp, out_perp))));
     return add(out_perp, out_parallel);
 }
 RTR_DEV float reflectance(float cosine, float idx) { // materials.rs:103-108; powi(x,5) = x*((x*x)*(x*x))
@@ -576,7 +595,16 @@ __global__ __launch_bounds__(64, RTR_X_WAVES_PER_EU) void k_render(const RenderP
 #ifdef RTR_X_COUNT_ITERS // diagnostic build only: the segment counter returns wave-iterations*64 instead
     uint32_t n_iter = 0;
 #endif
+#ifdef RTR_X_STAMPS // diagnostic build only: wave-cycle shares of the loop's sections -> counter ring slots 1..5
+    unsigned long long st_acc[5] = {0, 0, 0, 0, 0};
+    unsigned long long st_last = __builtin_amdgcn_s_memtime();
+#define RTR_STAMP(k) { __builtin_amdgcn_sched_barrier(0); unsigned long long st_now = __builtin_amdgcn_s_memtime(); \
+        __builtin_amdgcn_s_waitcnt(0xC07F); st_acc[k] += st_now - st_last; st_last = st_now; __builtin_amdgcn_sched_barrier(0); }
+#else
+#define RTR_STAMP(k)
+#endif
     while (s < spp) {
+        RTR_STAMP(4)
         // ---- trace_ray body (render.rs:32-59): one segment ----
         Hit h;
         nseg++;
@@ -585,7 +613,9 @@ __global__ __launch_bounds__(64, RTR_X_WAVES_PER_EU) void k_render(const RenderP
 #endif
         bool done;
         V3 term;
-        if (!world_hit<WORLD, NS>(p, ray, h, stk_ref, stk_t, lane, sr, lds_spheres)) {
+        const bool was_hit = world_hit<WORLD, NS>(p, ray, h, stk_ref, stk_t, lane, sr, lds_spheres);
+        RTR_STAMP(0)
+        if (!was_hit) {
             term = background(p, ray);
             done = true;
         } else if (p.mode == 3u) { // RenderMode::Normal, render.rs:42-45
@@ -615,6 +645,7 @@ __global__ __launch_bounds__(64, RTR_X_WAVES_PER_EU) void k_render(const RenderP
             }
             bool scattered = true;
             V3 ndir = h.normal;
+            RTR_STAMP(1)
             // Lambertian, Metal and Isotropic all start from one rejection-sampled point of the unit ball
             // (sample.rs:43-51) and it is their first draw after the mix walk, so the loop is run ONCE for all
             // three kinds (one divergent loop per segment instead of one per material kind).
@@ -622,8 +653,9 @@ __global__ __launch_bounds__(64, RTR_X_WAVES_PER_EU) void k_render(const RenderP
             if (kind == 0u || kind == 1u || kind == 5u) {
                 float m2;
                 sv = sample_unit_ball(rng, m2);
-                if (kind != 5u) sv = scale(sv, 1.0f / sqrtf(m2)); // sample_unit_sphere_surface, sample.rs:66-70
+                if (kind != 5u) sv = scale(sv, 1.0f / rt_sqrt(m2)); // sample_unit_sphere_surface, sample.rs:66-70
             }
+            RTR_STAMP(2)
             if (kind == 0u) { // Lambertian, materials.rs:31-41
                 ndir = add(h.normal, sv);
                 if (near_zero(ndir)) ndir = h.normal;
@@ -637,7 +669,7 @@ __global__ __launch_bounds__(64, RTR_X_WAVES_PER_EU) void k_render(const RenderP
                 float ratio = h.front_face ? 1.0f / param : param;
                 V3 unit = normalize(ray.d);
                 float cos_theta = fminf(dot(h.normal, neg(unit)), 1.0f);
-                float sin_theta = sqrtf(1.0f - cos_theta * cos_theta);
+                float sin_theta = rt_sqrt(1.0f - cos_theta * cos_theta);
                 bool cannot_refract = (ratio * sin_theta) > 1.0f;
                 bool refl = cannot_refract;
                 if (!refl) refl = reflectance(cos_theta, ratio) > rng_unit(rng); // no draw on TIR (short-circuit ||)
@@ -657,6 +689,7 @@ __global__ __launch_bounds__(64, RTR_X_WAVES_PER_EU) void k_render(const RenderP
                 done = true;
             }
         }
+        RTR_STAMP(1)
         if (done) {
             // attenuation * (attenuation * (... * terminal)), render.rs:52
             while (nchain > 0u) {
@@ -675,7 +708,12 @@ __global__ __launch_bounds__(64, RTR_X_WAVES_PER_EU) void k_render(const RenderP
             s++;
             if (s < spp) start_sample(s);
         }
+        RTR_STAMP(3)
     }
+#ifdef RTR_X_STAMPS
+    if (lane == 0 && p.spp > 1u) // scripts/stamps.py makes 5 one-sample launches first, so slots counter-1..-5 exist
+        for (int k = 0; k < 5; k++) atomicAdd(p.counter - 1 - k, st_acc[k]);
+#endif
 
     if (inside) {
         if (p.sum_rgba) {
@@ -728,6 +766,24 @@ __global__ __launch_bounds__(256) void k_resolve(const float *sum_rgba, uint32_t
         uint32_t r8 = sat_u8(sqrtf(r) * 255.0f), g8 = sat_u8(sqrtf(g) * 255.0f), b8 = sat_u8(sqrtf(b) * 255.0f);
         reinterpret_cast<uint32_t *>(rgba8)[i] = r8 | (g8 << 8) | (b8 << 16) | (255u << 24);
     }
+}
+
+// Exhaustive device self-test: rt_sqrt(x) against sqrtf(x) for every f32 bit pattern (NaNs compare as NaNs).
+__global__ __launch_bounds__(256) void k_selftest_sqrt(unsigned long long *mismatches) {
+    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x; // 2^20 threads x 4096 patterns
+    uint32_t bad = 0;
+    for (uint32_t i = 0; i < 4096u; i++) {
+        const float x = __uint_as_float(tid * 4096u + i);
+        const float a = rt_sqrt(x), b = sqrtf(x);
+        const bool same = (__float_as_uint(a) == __float_as_uint(b)) || (a != a && b != b);
+        bad += same ? 0u : 1u;
+    }
+    if (bad) atomicAdd(mismatches, (unsigned long long)bad);
+}
+
+hipError_t launch_selftest_sqrt(unsigned long long *d_mismatches, hipStream_t stream) {
+    hipLaunchKernelGGL(k_selftest_sqrt, dim3(4096), dim3(256), 0, stream, d_mismatches);
+    return hipGetLastError();
 }
 
 // --- launchers (called from rtr_api.cpp) -----------------------------------------------------------------

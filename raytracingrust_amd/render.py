@@ -149,6 +149,12 @@ class Renderer:
             self._check(n)
         return out[:n]
 
+    def selftest_sqrt(self) -> int:
+        """Mismatches between the kernels' sqrt and sqrtf() over all 2^32 f32 bit patterns (must be 0)."""
+        bad = C.c_uint64(0)
+        self._check(self._lib.rtr_selftest_sqrt(self._ctx, C.byref(bad)))
+        return int(bad.value)
+
     def segment_counts(self, cap: int = 64) -> np.ndarray:
         out = np.zeros(cap, dtype=np.uint64)
         n = self._lib.rtr_segment_counts(self._ctx, out.ctypes.data_as(C.POINTER(C.c_uint64)), cap)

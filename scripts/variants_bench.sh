@@ -1,7 +1,7 @@
 #!/bin/bash
 # time kernel variants built with `python -m raytracingrust_amd.build --variant NAME FLAGS...` (timing only)
 for v in "$@"; do
-  RTR_HIP_LIBRARY=$PWD/raytracingrust_amd/_lib/librtr_hip_$v.so timeout -k 10 200 python bench.py --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/bench_$v.log 2>&1
+  RTR_HIP_LIBRARY=$PWD/raytracingrust_amd/_lib/librtr_hip_$v.so timeout -k 10 200 python bench.py --steps 3 --warmup 1 --no-cpu-baseline $BENCH_ARGS > gpurun_out/bench_$v.log 2>&1
   python - "$v" <<'PY'
 import json, sys
 v = sys.argv[1]

@@ -11,70 +11,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 DATA = os.path.join(ROOT, "data")
 
 
-def scene_path(name: str) -> str:
-    return os.path.join(DATA, "scenes", name)
-
-
-def mesh_path(name: str) -> str:
-    return os.path.join(DATA, "meshes", name)
-
-
-def benchmark_scene(spp=8, **settings) -> rt.Scene:
-    s = rt.Scene.from_file(scene_path("benchmark.json"))
-    s.settings.samples_per_pixel = spp
-    for k, v in settings.items():
-        setattr(s.settings, k, v)
-    return s
-
-
-def simple_scene(spp=8, **settings) -> rt.Scene:
-    s = rt.Scene.from_file(scene_path("simple.json"))
-    s.settings.samples_per_pixel = spp
-    for k, v in settings.items():
-        setattr(s.settings, k, v)
-    return s
-
-
-def monkey_scene(spp=4, material=None, background=None, depth=6, bvh=True, with_plane=True) -> rt.Scene:
-    """BASELINE config C3 geometry: monkey.obj over plane.obj, camera (0,0,3)->(0,0,0), fov 60, 16:9."""
-    s = rt.Scene()
-    s.camera = rt.Camera([0.0, 0.0, 3.0], [0.0, 0.0, 0.0], [0.0, 1.0, 0.0], 60.0, 16.0 / 9.0)
-    s.settings.samples_per_pixel = spp
-    s.settings.max_ray_depth = depth
-    s.settings.enable_bvh_tree = bvh
-    s.background = background if background is not None else rt.GradientBackground([0.9, 0.9, 1.0], [0.3, 0.4, 0.8])
-    m = s.add_material(material if material is not None else rt.Lambertian([0.8, 0.5, 0.3]))
-    g = s.add_material(rt.Lambertian([0.4, 0.4, 0.4]))
-    mesh = rt.Mesh.from_file(mesh_path("monkey.obj"), m)
-    mesh.build_bvh()
-    s.add_object(mesh)
-    if with_plane:
-        plane = rt.Mesh.from_file(mesh_path("plane.obj"), g)
-        plane.positions = (plane.positions + np.array([0.0, -1.0, 0.0], dtype=np.float32)).astype(np.float32)
-        s.add_object(plane)
-    return s
-
-
-def house_scene(spp=2, depth=3, background=None) -> rt.Scene:
-    """BASELINE config C4: the scene src/gui.rs:56-119 builds (house.obj + plane.obj, mix ground)."""
-    s = rt.Scene()
-    s.camera = rt.Camera([-3.0, 2.0, 4.0], [0.0, 2.0, -1.0], [0.0, 1.0, 0.0], 90.0, 16.0 / 9.0)
-    s.settings.samples_per_pixel = spp
-    s.settings.max_ray_depth = depth
-    s.background = background if background is not None else rt.GradientBackground([1.0, 1.0, 1.0], [0.5, 0.7, 1.0])
-    lam = s.add_material(rt.Lambertian([0.9, 0.2, 0.2]))
-    s.add_material(rt.Metal([0.8, 0.2, 0.2], 0.02))
-    s.add_material(rt.Dielectric(1.5))
-    ground = s.add_material(rt.MixMaterial(rt.Metal([0.1, 0.1, 0.1], 0.0), rt.Lambertian([0.4, 0.4, 0.4]), 0.5))
-    s.add_material(rt.Emission([1.0, 1.0, 1.0], 50.0))
-    s.add_material(rt.Isotropic([1.0, 1.0, 1.0]))
-    house = rt.Mesh.from_file(mesh_path("house.obj"), lam)
-    house.build_bvh()
-    s.add_object(house)
-    plane = rt.Mesh.from_file(mesh_path("plane.obj"), ground)
-    plane.build_bvh()
-    s.add_object(plane)
-    return s
+from raytracingrust_amd.configs import (benchmark_scene, house_scene, mesh_path, monkey_scene, scene_path,  # noqa: F401,E402
+                                        simple_scene)
 
 
 def bits(a: np.ndarray) -> np.ndarray:
