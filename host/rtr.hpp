@@ -1,0 +1,446 @@
+// rtr.hpp -- C++ host-side mirror of RayTracingRust's scene surface over the C ABI (include/rtr_hip.h).
+//
+// The reference is compiled code (Rust); this image has no Rust toolchain, so the host side above the C ABI is
+// written in C++ (header-only, C++17) and keeps the reference's names, fields, defaults and error behaviour:
+//
+//   rtr::Scene / RenderSettings / RenderMode / MaterialHandle / ObjectHandle   lib/core/scene.rs:14-115
+//   rtr::Camera                                                                 lib/core/camera.rs:27-34
+//   rtr::Sphere                                                                 lib/objects.rs:15-20
+//   rtr::Mesh (from_file / from_buffers / build_bvh)                            lib/core/mesh.rs:31-121
+//   rtr::Lambertian / Metal / Emission / Dielectric / MixMaterial               lib/materials.rs
+//   rtr::Isotropic                                                              lib/volume.rs:75-88
+//   rtr::UniformBackground / GradientBackground / SkyMap                        lib/backgrounds.rs
+//   rtr::RenderTarget, rtr::render(target, scene)                               lib/core/render.rs:14-30,61
+//   rtr::Scene::from_file (scenes/*.json, serde + typetag schema)               lib/core/scene.rs:74-76
+//
+// Everything numerical (BVH build, intersection, shading, resolve) happens inside librtr_hip.so on the GPU; this
+// header only owns containers, parses the two input formats and lowers a Scene to the ABI's plain-old-data.
+// Errors: the reference panics; here they are std::runtime_error carrying the library's message.
+#pragma once
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <map>
+#include <memory>
+#include <random>
+#include <sstream>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../include/rtr_hip.h"
+
+namespace rtr {
+
+struct Vec3 { float x = 0, y = 0, z = 0; };   // lib/utils/types.rs:8 (cgmath Vector3<f32>)
+struct Color { float r = 0, g = 1, b = 0; };  // lib/utils/color.rs:6-11 (Default = green, color.rs:44-48)
+
+enum class RenderMode : uint32_t { Full = 0, Clay = 1, Random = 2, Normal = 3 }; // scene.rs:14-20
+
+struct RenderSettings { // scene.rs:22-30, defaults scene.rs:52-59
+    uint32_t samples_per_pixel = 5;
+    uint8_t max_ray_depth = 6;
+    float clamp_indirect = 10.0f;
+    bool enable_multithreading = true;
+    bool enable_bvh_tree = true;
+    RenderMode mode = RenderMode::Full;
+};
+
+struct Camera { // camera.rs:27-34, defaults scene.rs:45-51
+    Vec3 lookfrom{0, 0, 0}, lookat{0, 0, -1}, vertical{0, 1, 0};
+    float vertical_fov = 90.0f, aspect_ratio = 1.0f;
+};
+
+struct MaterialHandle { size_t index; }; // scene.rs:67-68
+struct ObjectHandle { size_t index; };   // scene.rs:70-71
+
+// ---- lowering target -----------------------------------------------------------------------------------------
+struct Lowered {
+    std::vector<rtr_object> objects;
+    std::vector<rtr_sphere> spheres;
+    std::vector<rtr_mesh> meshes;
+    std::vector<rtr_material> materials;
+    rtr_background background{};
+    rtr_scene_desc desc() const {
+        rtr_scene_desc d{};
+        d.objects = objects.data(); d.n_objects = (uint32_t)objects.size();
+        d.spheres = spheres.data(); d.n_spheres = (uint32_t)spheres.size();
+        d.meshes = meshes.data(); d.n_meshes = (uint32_t)meshes.size();
+        d.materials = materials.data(); d.n_materials = (uint32_t)materials.size();
+        d.background = background;
+        return d;
+    }
+};
+
+// ---- materials (lib/materials.rs) ----------------------------------------------------------------------------
+class Material {
+  public:
+    virtual ~Material() = default;
+    // writes this material into out[slot]; nested children are appended after the existing entries
+    virtual void lower(std::vector<rtr_material> &out, size_t slot) const = 0;
+  protected:
+    static rtr_material make(uint32_t kind, Color c, float param) {
+        rtr_material m{};
+        m.kind = kind; m.rgb[0] = c.r; m.rgb[1] = c.g; m.rgb[2] = c.b; m.param = param;
+        return m;
+    }
+};
+class Lambertian : public Material { // materials.rs:18-42
+  public:
+    explicit Lambertian(Color albedo) : albedo(albedo) {}
+    Color albedo;
+    void lower(std::vector<rtr_material> &out, size_t slot) const override { out[slot] = make(RTR_MAT_LAMBERTIAN, albedo, 0); }
+};
+class Metal : public Material { // materials.rs:44-71
+  public:
+    Metal(Color albedo, float fuzz) : albedo(albedo), fuzz(fuzz) {}
+    Color albedo; float fuzz;
+    void lower(std::vector<rtr_material> &out, size_t slot) const override { out[slot] = make(RTR_MAT_METAL, albedo, fuzz); }
+};
+class Emission : public Material { // materials.rs:73-91: colour pre-multiplied by strength
+  public:
+    Emission(Color c, float strength) : color{c.r * strength, c.g * strength, c.b * strength} {}
+    Color color;
+    void lower(std::vector<rtr_material> &out, size_t slot) const override { out[slot] = make(RTR_MAT_EMISSION, color, 0); }
+};
+class Dielectric : public Material { // materials.rs:93-139
+  public:
+    explicit Dielectric(float ir) : ir(ir) {}
+    float ir;
+    void lower(std::vector<rtr_material> &out, size_t slot) const override { out[slot] = make(RTR_MAT_DIELECTRIC, Color{0, 0, 0}, ir); }
+};
+class Isotropic : public Material { // volume.rs:75-88
+  public:
+    explicit Isotropic(Color c) : color(c) {}
+    Color color;
+    void lower(std::vector<rtr_material> &out, size_t slot) const override { out[slot] = make(RTR_MAT_ISOTROPIC, color, 0); }
+};
+class MixMaterial : public Material { // materials.rs:141-157: xi >= factor picks `first`
+  public:
+    MixMaterial(std::unique_ptr<Material> first, std::unique_ptr<Material> second, float factor)
+        : first(std::move(first)), second(std::move(second)), factor(factor) {}
+    std::unique_ptr<Material> first, second;
+    float factor;
+    void lower(std::vector<rtr_material> &out, size_t slot) const override {
+        out[slot] = make(RTR_MAT_MIX, Color{0, 0, 0}, factor);
+        size_t a = out.size(); out.emplace_back(); first->lower(out, a);
+        size_t b = out.size(); out.emplace_back(); second->lower(out, b);
+        out[slot].first = (uint32_t)a; out[slot].second = (uint32_t)b;
+    }
+};
+
+// ---- objects -------------------------------------------------------------------------------------------------
+class Object { // lib/core/traits.rs:18-21
+  public:
+    virtual ~Object() = default;
+    virtual MaterialHandle material() const = 0;
+    virtual void lower(Lowered &out) const = 0;
+};
+class Sphere : public Object { // objects.rs:15-20
+  public:
+    Sphere(Vec3 center, float radius, MaterialHandle material) : center(center), radius(radius), mat(material) {}
+    Vec3 center; float radius; MaterialHandle mat;
+    MaterialHandle material() const override { return mat; }
+    void lower(Lowered &out) const override {
+        rtr_sphere s{}; s.center[0] = center.x; s.center[1] = center.y; s.center[2] = center.z; s.radius = radius;
+        s.material = (uint32_t)mat.index;
+        out.objects.push_back(rtr_object{RTR_OBJ_SPHERE, (uint32_t)out.spheres.size()});
+        out.spheres.push_back(s);
+    }
+};
+
+// The subset of obj-rs 0.7 load_obj::<obj::Vertex,u32> the reference uses (mesh.rs:63-66): triangulated faces with
+// normals; one vertex per distinct (position index, normal index) pair in first-appearance order.
+inline void load_obj(const std::string &path, std::vector<float> &positions, std::vector<float> &normals, std::vector<uint32_t> &indices) {
+    std::ifstream in(path);
+    if (!in) throw std::runtime_error("cannot open " + path); // File::open(path).unwrap(), mesh.rs:65
+    std::vector<float> pos, nrm;
+    std::map<std::pair<long, long>, uint32_t> seen;
+    std::string line;
+    auto num = [](const std::string &t) { return (float)std::strtod(t.c_str(), nullptr); };
+    while (std::getline(in, line)) {
+        std::istringstream ls(line);
+        std::string tag; ls >> tag;
+        if (tag == "v" || tag == "vn") {
+            std::string a, b, c; ls >> a >> b >> c;
+            std::vector<float> &dst = tag == "v" ? pos : nrm;
+            dst.push_back(num(a)); dst.push_back(num(b)); dst.push_back(num(c));
+        } else if (tag == "f") {
+            std::vector<std::string> toks; std::string t;
+            while (ls >> t) toks.push_back(t);
+            if (toks.size() != 3) throw std::runtime_error(path + ": only triangulated faces are supported");
+            for (const std::string &tok : toks) {
+                size_t s1 = tok.find('/'), s2 = s1 == std::string::npos ? s1 : tok.find('/', s1 + 1);
+                if (s2 == std::string::npos || s2 + 1 >= tok.size()) throw std::runtime_error(path + ": face vertex without a normal");
+                long pi = std::strtol(tok.substr(0, s1).c_str(), nullptr, 10), ni = std::strtol(tok.substr(s2 + 1).c_str(), nullptr, 10);
+                pi = pi > 0 ? pi - 1 : (long)(pos.size() / 3) + pi;
+                ni = ni > 0 ? ni - 1 : (long)(nrm.size() / 3) + ni;
+                auto key = std::make_pair(pi, ni);
+                auto it = seen.find(key);
+                if (it == seen.end()) {
+                    it = seen.emplace(key, (uint32_t)(positions.size() / 3)).first;
+                    for (int k = 0; k < 3; k++) { positions.push_back(pos[3 * pi + k]); normals.push_back(nrm[3 * ni + k]); }
+                }
+                indices.push_back(it->second);
+            }
+        }
+    }
+}
+
+class Mesh : public Object { // mesh.rs:31-121
+  public:
+    static std::unique_ptr<Mesh> from_file(const std::string &path, MaterialHandle material) {
+        auto m = std::make_unique<Mesh>();
+        load_obj(path, m->positions, m->normals, m->indices);
+        m->mat = material;
+        return m;
+    }
+    static std::unique_ptr<Mesh> from_buffers(std::vector<float> positions, std::vector<float> normals, std::vector<uint32_t> indices, MaterialHandle material) {
+        auto m = std::make_unique<Mesh>();
+        m->positions = std::move(positions); m->normals = std::move(normals); m->indices = std::move(indices); m->mat = material;
+        return m;
+    }
+    void build_bvh() {} // Mesh::build_bvh (mesh.rs:119-121): the library builds the tree at upload
+    std::vector<float> positions, normals; // n_verts*3 each
+    std::vector<uint32_t> indices;         // n_tris*3
+    MaterialHandle mat{0};
+    MaterialHandle material() const override { return mat; }
+    void lower(Lowered &out) const override {
+        rtr_mesh m{};
+        m.positions = positions.data(); m.normals = normals.data(); m.indices = indices.data();
+        m.n_verts = (uint32_t)(positions.size() / 3); m.n_tris = (uint32_t)(indices.size() / 3); m.material = (uint32_t)mat.index;
+        out.objects.push_back(rtr_object{RTR_OBJ_MESH, (uint32_t)out.meshes.size()});
+        out.meshes.push_back(m);
+    }
+};
+
+// ---- backgrounds (lib/backgrounds.rs) ------------------------------------------------------------------------
+class Background {
+  public:
+    virtual ~Background() = default;
+    virtual void lower(rtr_background &out) const = 0;
+};
+class UniformBackground : public Background {
+  public:
+    explicit UniformBackground(Color c) : color(c) {}
+    Color color;
+    void lower(rtr_background &o) const override { o = rtr_background{}; o.kind = RTR_BG_UNIFORM; o.a[0] = color.r; o.a[1] = color.g; o.a[2] = color.b; }
+};
+class GradientBackground : public Background {
+  public:
+    GradientBackground(Color top, Color bottom) : top(top), bottom(bottom) {}
+    Color top, bottom;
+    void lower(rtr_background &o) const override {
+        o = rtr_background{}; o.kind = RTR_BG_GRADIENT;
+        o.a[0] = top.r; o.a[1] = top.g; o.a[2] = top.b; o.b[0] = bottom.r; o.b[1] = bottom.g; o.b[2] = bottom.b;
+    }
+};
+class SkyMap : public Background { // backgrounds.rs:51-56: row-major texels, row 0 = top scanline
+  public:
+    SkyMap(std::vector<float> rgb, uint32_t width, uint32_t height) : image(std::move(rgb)), width(width), height(height) {
+        if (image.size() != (size_t)width * height * 3 || image.empty()) throw std::runtime_error("SkyMap: image must hold width*height RGB triples");
+    }
+    std::vector<float> image; uint32_t width, height;
+    void lower(rtr_background &o) const override { o = rtr_background{}; o.kind = RTR_BG_SKYMAP; o.image = image.data(); o.width = width; o.height = height; }
+};
+
+// ---- a small JSON reader for scenes/*.json (serde_json + typetag layout) ---------------
+namespace json {
+struct Value {
+    enum Kind { Null, Bool, Number, String, Array, Object } kind = Null;
+    bool b = false; double n = 0; std::string s;
+    std::vector<Value> a; std::vector<std::pair<std::string, Value>> o;
+    const Value &at(const std::string &k) const {
+        for (auto &kv : o) if (kv.first == k) return kv.second;
+        throw std::runtime_error("missing field `" + k + "`"); // serde: missing field -> Err -> unwrap panics (scene.rs:75)
+    }
+    const Value *find(const std::string &k) const { for (auto &kv : o) if (kv.first == k) return &kv.second; return nullptr; }
+    float f() const { if (kind != Number) throw std::runtime_error("expected a number"); return (float)n; } // f64 -> `as f32`
+};
+class Parser {
+  public:
+    explicit Parser(const std::string &t) : t(t) {}
+    Value parse() { Value v = value(); ws(); if (i != t.size()) fail("trailing characters"); return v; }
+  private:
+    const std::string &t; size_t i = 0;
+    [[noreturn]] void fail(const char *m) const { throw std::runtime_error(std::string("scene JSON: ") + m + " at offset " + std::to_string(i)); }
+    void ws() { while (i < t.size() && (t[i] == ' ' || t[i] == '\n' || t[i] == '\t' || t[i] == '\r')) i++; }
+    bool eat(char c) { ws(); if (i < t.size() && t[i] == c) { i++; return true; } return false; }
+    Value value() {
+        ws(); if (i >= t.size()) fail("unexpected end");
+        char c = t[i]; Value v;
+        if (c == '{') { i++; v.kind = Value::Object; if (eat('}')) return v;
+            do { ws(); Value k = string(); if (!eat(':')) fail("expected ':'"); v.o.emplace_back(k.s, value()); } while (eat(','));
+            if (!eat('}')) fail("expected '}'"); return v; }
+        if (c == '[') { i++; v.kind = Value::Array; if (eat(']')) return v;
+            do { v.a.push_back(value()); } while (eat(','));
+            if (!eat(']')) fail("expected ']'"); return v; }
+        if (c == '"') return string();
+        if (t.compare(i, 4, "true") == 0) { i += 4; v.kind = Value::Bool; v.b = true; return v; }
+        if (t.compare(i, 5, "false") == 0) { i += 5; v.kind = Value::Bool; return v; }
+        if (t.compare(i, 4, "null") == 0) { i += 4; return v; }
+        char *end = nullptr; v.n = std::strtod(t.c_str() + i, &end);
+        if (end == t.c_str() + i) fail("bad token"); i = (size_t)(end - t.c_str()); v.kind = Value::Number; return v;
+    }
+    Value string() {
+        if (i >= t.size() || t[i] != '"') fail("expected string"); i++; Value v; v.kind = Value::String;
+        while (i < t.size() && t[i] != '"') { if (t[i] == '\\' && i + 1 < t.size()) i++; v.s.push_back(t[i++]); }
+        if (i >= t.size()) fail("unterminated string"); i++; return v;
+    }
+};
+} // namespace json
+
+// ---- Scene (lib/core/scene.rs:32-115) --------------------------------------------------------------------------
+class Scene {
+  public:
+    Camera camera;
+    RenderSettings settings;
+    std::unique_ptr<Background> background = std::make_unique<UniformBackground>(Color{0.8f, 0.8f, 0.8f}); // scene.rs:60
+    std::vector<std::unique_ptr<Object>> objects;
+
+    ObjectHandle add_object(std::unique_ptr<Object> o) { objects.push_back(std::move(o)); return ObjectHandle{objects.size() - 1}; }         // scene.rs:87-90
+    MaterialHandle add_material(std::unique_ptr<Material> m) { materials_.push_back(std::move(m)); return MaterialHandle{materials_.size() - 1}; } // scene.rs:100-103
+    const Material &material(MaterialHandle h) const { return *materials_.at(h.index); }
+    size_t material_count() const { return materials_.size(); }
+
+    // Scene::from_file (scene.rs:74-76).  settings.clamp_indirect is absent from both shipped scene files, which
+    // makes the reference's own loader fail; it defaults to Scene::default()'s 10.0 here.
+    static Scene from_file(const std::string &path) {
+        std::ifstream in(path);
+        if (!in) throw std::runtime_error("cannot open " + path);
+        std::stringstream ss; ss << in.rdbuf();
+        return from_json(ss.str());
+    }
+    static Scene from_json(const std::string &text) {
+        json::Value doc = json::Parser(text).parse();
+        Scene s;
+        const json::Value &c = doc.at("camera");
+        s.camera.lookfrom = xyz(c.at("lookfrom")); s.camera.lookat = xyz(c.at("lookat")); s.camera.vertical = xyz(c.at("vertical"));
+        s.camera.vertical_fov = c.at("vertical_fov").f(); s.camera.aspect_ratio = c.at("aspect_ratio").f();
+        const json::Value &st = doc.at("settings");
+        s.settings.samples_per_pixel = (uint32_t)st.at("samples_per_pixel").n;
+        s.settings.max_ray_depth = (uint8_t)st.at("max_ray_depth").n;
+        if (const json::Value *ci = st.find("clamp_indirect")) s.settings.clamp_indirect = ci->f();
+        s.settings.enable_multithreading = st.at("enable_multithreading").b;
+        s.settings.enable_bvh_tree = st.at("enable_bvh_tree").b;
+        const std::string &mode = st.at("mode").s;
+        s.settings.mode = mode == "Full" ? RenderMode::Full : mode == "Clay" ? RenderMode::Clay : mode == "Random" ? RenderMode::Random
+                        : mode == "Normal" ? RenderMode::Normal : throw std::runtime_error("unknown RenderMode " + mode);
+        const json::Value &bg = doc.at("background");
+        const std::string &bt = bg.at("type").s;
+        if (bt == "UniformBackground") s.background = std::make_unique<UniformBackground>(rgb(bg.at("color")));
+        else if (bt == "GradientBackground") s.background = std::make_unique<GradientBackground>(rgb(bg.at("top")), rgb(bg.at("bottom")));
+        else if (bt == "SkyMap") {
+            std::vector<float> img;
+            for (const json::Value &p : bg.at("image").a) { Color col = rgb(p); img.push_back(col.r); img.push_back(col.g); img.push_back(col.b); }
+            s.background = std::make_unique<SkyMap>(std::move(img), (uint32_t)bg.at("width").n, (uint32_t)bg.at("height").n);
+        } else throw std::runtime_error("unknown background type " + bt);
+        for (const json::Value &m : doc.at("materials").a) s.add_material(material_from(m));
+        for (const json::Value &o : doc.at("objects").a) {
+            const std::string &ot = o.at("type").s;
+            if (ot == "Sphere") s.add_object(std::make_unique<Sphere>(xyz(o.at("center")), o.at("radius").f(), MaterialHandle{(size_t)o.at("material").n}));
+            else if (ot == "Mesh") throw std::runtime_error("Mesh cannot be deserialized (the reference panics: mesh.rs:51-60)");
+            else throw std::runtime_error("object type " + ot + " is outside the GPU path");
+        }
+        return s;
+    }
+
+    // Lower to the ABI's plain-old-data.  `out` borrows the mesh / sky buffers of this scene: keep the scene alive.
+    void lower(Lowered &out) const {
+        out = Lowered{};
+        out.materials.resize(materials_.size());
+        for (size_t i = 0; i < materials_.size(); i++) materials_[i]->lower(out.materials, i);
+        for (auto &o : objects) o->lower(out);
+        background->lower(out.background);
+    }
+
+  private:
+    std::vector<std::unique_ptr<Material>> materials_; // private in the reference too (scene.rs:39)
+    static Vec3 xyz(const json::Value &v) { return Vec3{v.at("x").f(), v.at("y").f(), v.at("z").f()}; }
+    static Color rgb(const json::Value &v) { return Color{v.at("r").f(), v.at("g").f(), v.at("b").f()}; }
+    static std::unique_ptr<Material> material_from(const json::Value &m) {
+        const std::string &t = m.at("type").s;
+        if (t == "Lambertian") return std::make_unique<Lambertian>(rgb(m.at("albedo")));
+        if (t == "Metal") return std::make_unique<Metal>(rgb(m.at("albedo")), m.at("fuzz").f());
+        if (t == "Emission") return std::make_unique<Emission>(rgb(m.at("color")), 1.0f);
+        if (t == "Dielectric") return std::make_unique<Dielectric>(m.at("ir").f());
+        if (t == "Isotropic") return std::make_unique<Isotropic>(rgb(m.at("color")));
+        if (t == "MixMaterial") return std::make_unique<MixMaterial>(material_from(m.at("first")), material_from(m.at("second")), m.at("factor").f());
+        throw std::runtime_error("unknown material type " + t);
+    }
+};
+
+// ---- RenderTarget + render (lib/core/render.rs:14-30, 61) -----------------------------------------------------
+struct RenderTarget {
+    size_t width, height;
+    std::vector<uint8_t> data;
+    bool request_redraw = false;
+    RenderTarget(size_t w, size_t h) : width(w), height(h), data(w * h * 4, 0) {}
+};
+
+// One rtr_context: amortises the scene upload over many frames.  device = -1: host-only (lowering + BVH only).
+class Renderer {
+  public:
+    explicit Renderer(int device = 0) {
+        if (rtr_create(device, &ctx_) != RTR_OK) throw std::runtime_error(std::string("rtr_create: ") + rtr_last_error(nullptr));
+    }
+    ~Renderer() { rtr_destroy(ctx_); }
+    Renderer(const Renderer &) = delete;
+    Renderer &operator=(const Renderer &) = delete;
+    void upload(const Scene &scene) {
+        Lowered l; scene.lower(l);
+        rtr_scene_desc d = l.desc();
+        check(rtr_upload_scene(ctx_, &d), "rtr_upload_scene");
+    }
+    void render(const Scene &scene, RenderTarget &target, uint64_t seed) {
+        rtr_camera c = camera_of(scene); rtr_settings s = settings_of(scene);
+        check(rtr_render_rgba8(ctx_, &c, &s, (uint32_t)target.width, (uint32_t)target.height, seed, target.data.data()), "rtr_render_rgba8");
+    }
+    void render_f32(const Scene &scene, size_t width, size_t height, uint64_t seed, std::vector<float> &mean_rgb) {
+        rtr_camera c = camera_of(scene); rtr_settings s = settings_of(scene);
+        mean_rgb.assign(width * height * 3, 0.0f);
+        check(rtr_render_f32(ctx_, &c, &s, (uint32_t)width, (uint32_t)height, seed, mean_rgb.data()), "rtr_render_f32");
+    }
+    rtr_scene_info info() { rtr_scene_info i{}; check(rtr_scene_info_get(ctx_, &i), "rtr_scene_info_get"); return i; }
+    rtr_stats stats() { rtr_stats s{}; check(rtr_get_stats(ctx_, &s), "rtr_get_stats"); return s; }
+    rtr_context *raw() { return ctx_; }
+    static rtr_camera camera_of(const Scene &sc) {
+        rtr_camera c{};
+        const Camera &k = sc.camera;
+        c.lookfrom[0] = k.lookfrom.x; c.lookfrom[1] = k.lookfrom.y; c.lookfrom[2] = k.lookfrom.z;
+        c.lookat[0] = k.lookat.x; c.lookat[1] = k.lookat.y; c.lookat[2] = k.lookat.z;
+        c.vertical[0] = k.vertical.x; c.vertical[1] = k.vertical.y; c.vertical[2] = k.vertical.z;
+        c.vertical_fov = k.vertical_fov; c.aspect_ratio = k.aspect_ratio;
+        return c;
+    }
+    static rtr_settings settings_of(const Scene &sc) {
+        rtr_settings s{};
+        s.samples_per_pixel = sc.settings.samples_per_pixel; s.max_ray_depth = sc.settings.max_ray_depth;
+        s.clamp_indirect = sc.settings.clamp_indirect; s.enable_multithreading = sc.settings.enable_multithreading;
+        s.enable_bvh_tree = sc.settings.enable_bvh_tree; s.mode = (uint32_t)sc.settings.mode;
+        return s;
+    }
+  private:
+    rtr_context *ctx_ = nullptr;
+    void check(int rc, const char *what) { if (rc != RTR_OK) throw std::runtime_error(std::string(what) + ": " + rtr_last_error(ctx_)); }
+};
+
+// lib/core/render.rs:61.  Like the reference, the acceleration structure is rebuilt on every call (render.rs:67) and
+// the random stream is freshly seeded (thread_rng is OS-seeded); pass `seed` for a reproducible frame.
+inline void render(RenderTarget &target, const Scene &scene, uint64_t seed, int device = 0) {
+    target.request_redraw = true;
+    Renderer r(device);
+    r.upload(scene);
+    r.render(scene, target, seed);
+}
+inline void render(RenderTarget &target, const Scene &scene) {
+    std::random_device rd;
+    render(target, scene, ((uint64_t)rd() << 32) | rd());
+}
+
+} // namespace rtr

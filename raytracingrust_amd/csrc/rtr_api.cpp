@@ -24,6 +24,10 @@ hipError_t render_kernel_attributes(const RenderParams &p, int *vgprs, int *stat
 hipError_t launch_selftest_sqrt(unsigned long long *d_mismatches, hipStream_t stream);
 } // namespace rtr
 
+#ifndef RTR_BVH_LDS_MATERIALS
+#define RTR_BVH_LDS_MATERIALS 16u
+#endif
+
 namespace {
 constexpr int kRing = 64;
 thread_local std::string g_create_error;
@@ -155,7 +159,10 @@ int launch_frame(rtr_context *ctx, const rtr_camera *camera, const rtr_settings 
     uint32_t grid = p.tiles_total > shard ? (p.tiles_total - shard + n_shards - 1u) / n_shards : 0u;
     // small tables staged in LDS: the linear sphere world's records, and the materials when they fit 4 KB
     p.sphere_regs = (p.world == rtr::WORLD_LINEAR_SPHERES && fs.n_objects >= 1u && fs.n_objects <= 8u) ? fs.n_objects : 0u;
-    p.lds_materials = (p.n_materials > 0u && p.n_materials <= 128u) ? p.n_materials : 0u;
+    // materials go to LDS when that does not cost occupancy: always for the register-bound sphere kernel, only
+    // small tables for the latency-bound tree kernels (their traversal stack already takes ~8 KB per wave)
+    const uint32_t lds_mat_cap = (p.world == rtr::WORLD_LINEAR_SPHERES) ? 128u : RTR_BVH_LDS_MATERIALS;
+    p.lds_materials = (p.n_materials > 0u && p.n_materials <= lds_mat_cap) ? p.n_materials : 0u;
     // dynamic LDS per wave: attenuation chain + traversal stack (refs + entry distances) + the tables
     uint32_t lds_bytes = (p.max_depth + 2u * p.stack_cap) * 64u * 4u + (p.sphere_regs + p.lds_materials) * 32u;
     if (lds_bytes > 160u * 1024u) return fail(ctx, RTR_ERR_UNSUPPORTED, "max_ray_depth + tree height exceed one CU's LDS");
