@@ -84,7 +84,7 @@ def main():
     import torch.distributed as dist
 
     import raytracingrust_amd as rt
-    from raytracingrust_amd.distributed import render_frame_distributed
+    from raytracingrust_amd.distributed import FramePipeline
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -116,7 +116,8 @@ def main():
     r = rt.Renderer(local_rank)
     r.upload_scene(scene)
     rgba8 = torch.zeros((H, W, 4), dtype=torch.uint8, device=dev)
-    accum = torch.zeros((H, W, 4), dtype=torch.float32, device=dev) if distributed else None
+    # N > 1: double-buffered integrate | RCCL reduce + resolve pipeline (raytracingrust_amd/distributed.py)
+    pipe = FramePipeline(r, W, H, args.spp, dev) if distributed else None
     # one explicit HIP stream for kernels, torch ops and RCCL alike (a NULL stream would mean "the context's own")
     tstream = torch.cuda.Stream(device=dev)
     torch.cuda.synchronize()
@@ -128,10 +129,13 @@ def main():
         if not distributed:
             r.render_frame_device(W, H, seed, rgba8.data_ptr(), stream)
         else:
-            # zero -> integrate own tiles -> RCCL reduce(SUM) to rank 0 -> resolve on rank 0
-            render_frame_distributed(r, W, H, seed, accum, rgba8 if rank == 0 else None, stream=stream, spp=args.spp)
+            # zero -> integrate own tiles -> RCCL reduce(SUM) to rank 0 -> resolve on rank 0, frame i's reduce
+            # overlapping frame i+1's integrate
+            pipe.submit(seed)
 
     def fence():
+        if pipe is not None:
+            pipe.wait()
         torch.cuda.synchronize()
         if distributed:
             dist.barrier()

@@ -58,3 +58,49 @@ def render_frame_distributed(renderer, width: int, height: int, seed: int, accum
         else:
             resolve(accum, spp, rgba8)
     return accum
+
+
+class FramePipeline:
+    """Double-buffered multi-GPU frames: the RCCL reduce (+ rank 0's resolve) of frame i runs on a communication
+    stream while the integrate kernel of frame i+1 runs on the compute stream, so a frame costs
+    max(integrate, reduce) instead of their sum.  Two float4 sum buffers alternate; HIP events order
+    zero -> integrate -> reduce -> resolve -> reuse.  Results are identical to `render_frame_distributed`."""
+
+    def __init__(self, renderer, width: int, height: int, spp: int, device, group=None):
+        import torch
+        import torch.distributed as dist
+
+        self.torch, self.dist = torch, dist
+        self.r, self.w, self.h, self.spp, self.group = renderer, width, height, spp, group
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        self.accum = [torch.zeros((height, width, 4), dtype=torch.float32, device=device) for _ in range(2)]
+        self.rgba8 = torch.zeros((height, width, 4), dtype=torch.uint8, device=device) if self.rank == 0 else None
+        self.compute = torch.cuda.Stream(device=device)
+        self.comm = torch.cuda.Stream(device=device)
+        self.rendered = [torch.cuda.Event() for _ in range(2)]
+        self.free = [torch.cuda.Event() for _ in range(2)]
+        self.n = 0
+        torch.cuda.synchronize(device)
+
+    def submit(self, seed: int) -> None:
+        torch, dist = self.torch, self.dist
+        b = self.n % 2
+        with torch.cuda.stream(self.compute):
+            if self.n >= 2:
+                self.compute.wait_event(self.free[b])  # frame n-2 has left this buffer
+            self.accum[b].zero_()
+            self.r.render_tiles_device(self.w, self.h, seed, self.rank, self.world, self.accum[b].data_ptr(),
+                                       self.compute.cuda_stream)
+            self.rendered[b].record(self.compute)
+        with torch.cuda.stream(self.comm):
+            self.comm.wait_event(self.rendered[b])
+            dist.reduce(self.accum[b], dst=0, op=dist.ReduceOp.SUM, group=self.group)
+            if self.rank == 0:
+                self.r.resolve_device(self.accum[b].data_ptr(), self.spp, self.w, self.h, self.rgba8.data_ptr(), 0,
+                                      self.comm.cuda_stream)
+            self.free[b].record(self.comm)
+        self.n += 1
+
+    def wait(self) -> None:
+        self.compute.synchronize()
+        self.comm.synchronize()

@@ -161,3 +161,42 @@ def test_full_size_frame_properties(gpu_renderer):
     assert np.all(a[:40, 600:1300, :3] == 197)  # sky: trunc(sqrt(0.6)*255)
     n = 1920 * 1080 * 2
     assert n <= seg <= n * scene.settings.max_ray_depth
+
+
+def test_frame_pipeline_over_rccl_single_rank(gpu_renderer):
+    """raytracingrust_amd.distributed.FramePipeline (what bench.py runs for N > 1) with a one-rank RCCL group:
+    double-buffered zero -> integrate -> reduce -> resolve must reproduce the fused frame for every frame."""
+    import os
+
+    import torch
+    import torch.distributed as dist
+
+    from raytracingrust_amd.distributed import FramePipeline
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29547")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        w, h = 120, 72
+        scene = benchmark_scene(6)
+        r = gpu_renderer
+        r.upload_scene(scene)
+        pipe = FramePipeline(r, w, h, scene.settings.samples_per_pixel, dev)
+        frames = []
+        for i in range(5):
+            pipe.submit(100 + i)
+            if i >= 3:  # read back the last frames one at a time (rgba8 is overwritten by the next resolve)
+                pipe.wait()
+                frames.append((100 + i, pipe.rgba8.cpu().numpy().copy()))
+        pipe.wait()
+        for seed, img in frames:
+            ref, _ = r.render(w, h, seed=seed)
+            assert np.array_equal(img, ref)
+    finally:
+        if created:
+            dist.destroy_process_group()
