@@ -8,7 +8,7 @@
 //   rtr::Sphere                                                                 lib/objects.rs:15-20
 //   rtr::Mesh (from_file / from_buffers / build_bvh)                            lib/core/mesh.rs:31-121
 //   rtr::Lambertian / Metal / Emission / Dielectric / MixMaterial               lib/materials.rs
-//   rtr::Isotropic                                                              lib/volume.rs:75-88
+//   rtr::Volume / Isotropic                                                     lib/volume.rs:19-32,75-88
 //   rtr::UniformBackground / GradientBackground / SkyMap                        lib/backgrounds.rs
 //   rtr::RenderTarget, rtr::render(target, scene)                               lib/core/render.rs:14-30,61
 //   rtr::Scene::from_file (scenes/*.json, serde + typetag schema)               lib/core/scene.rs:74-76
@@ -65,6 +65,7 @@ struct Lowered {
     std::vector<rtr_sphere> spheres;
     std::vector<rtr_mesh> meshes;
     std::vector<rtr_material> materials;
+    std::vector<rtr_volume> volumes;
     rtr_background background{};
     rtr_scene_desc desc() const {
         rtr_scene_desc d{};
@@ -73,6 +74,7 @@ struct Lowered {
         d.meshes = meshes.data(); d.n_meshes = (uint32_t)meshes.size();
         d.materials = materials.data(); d.n_materials = (uint32_t)materials.size();
         d.background = background;
+        d.volumes = volumes.data(); d.n_volumes = (uint32_t)volumes.size();
         return d;
     }
 };
@@ -151,6 +153,21 @@ class Sphere : public Object { // objects.rs:15-20
         s.material = (uint32_t)mat.index;
         out.objects.push_back(rtr_object{RTR_OBJ_SPHERE, (uint32_t)out.spheres.size()});
         out.spheres.push_back(s);
+    }
+};
+
+class Volume : public Object { // volume.rs:19-32 (sphere boundaries on the GPU path)
+  public:
+    Volume(Sphere boundary, float density) : boundary(std::move(boundary)), neg_inv_density(-1.0f / density) {}
+    Sphere boundary; float neg_inv_density;
+    MaterialHandle material() const override { return boundary.material(); } // volume.rs:98-100
+    void lower(Lowered &out) const override {
+        rtr_volume v{};
+        v.boundary.center[0] = boundary.center.x; v.boundary.center[1] = boundary.center.y; v.boundary.center[2] = boundary.center.z;
+        v.boundary.radius = boundary.radius; v.boundary.material = (uint32_t)boundary.mat.index;
+        v.neg_inv_density = neg_inv_density;
+        out.objects.push_back(rtr_object{RTR_OBJ_VOLUME, (uint32_t)out.volumes.size()});
+        out.volumes.push_back(v);
     }
 };
 
@@ -345,7 +362,13 @@ class Scene {
             const std::string &ot = o.at("type").s;
             if (ot == "Sphere") s.add_object(std::make_unique<Sphere>(xyz(o.at("center")), o.at("radius").f(), MaterialHandle{(size_t)o.at("material").n}));
             else if (ot == "Mesh") throw std::runtime_error("Mesh cannot be deserialized (the reference panics: mesh.rs:51-60)");
-            else throw std::runtime_error("object type " + ot + " is outside the GPU path");
+            else if (ot == "Volume") {
+                const json::Value &b = o.at("boundary");
+                if (b.at("type").s != "Sphere") throw std::runtime_error("Volume boundaries other than Sphere are outside the GPU path");
+                auto v = std::make_unique<Volume>(Sphere(xyz(b.at("center")), b.at("radius").f(), MaterialHandle{(size_t)b.at("material").n}), 1.0f);
+                v->neg_inv_density = o.at("neg_inv_density").f();
+                s.add_object(std::move(v));
+            } else throw std::runtime_error("unknown object type " + ot);
         }
         return s;
     }

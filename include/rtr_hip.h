@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define RTR_ABI_VERSION 1
+#define RTR_ABI_VERSION 2
 
 typedef enum rtr_status {
     RTR_OK = 0,
@@ -54,7 +54,7 @@ typedef enum rtr_status {
     RTR_ERR_NAN_CENTROID = -5,     /* partial_cmp().unwrap() in the BVH builder would panic (bvh.rs:99,109,119) */
     RTR_ERR_BAD_SETTINGS = -6,     /* clamp_indirect NaN/negative (f32::clamp panics, render.rs:95), empty target */
     RTR_ERR_NO_SCENE = -7,         /* render before rtr_upload_scene */
-    RTR_ERR_UNSUPPORTED = -8,      /* scene feature outside the GPU path (Volume objects: SURVEY section 8f N3) */
+    RTR_ERR_UNSUPPORTED = -8,      /* scene feature outside the GPU path (Volume with a mesh boundary, LDS budget) */
     RTR_ERR_OUT_OF_MEMORY = -9
 } rtr_status;
 
@@ -69,7 +69,7 @@ typedef enum rtr_material_kind {
     RTR_MAT_ISOTROPIC = 5   /* rgb = color                      volume.rs:75-88 */
 } rtr_material_kind;
 
-typedef enum rtr_object_kind { RTR_OBJ_SPHERE = 0, RTR_OBJ_MESH = 1 } rtr_object_kind;
+typedef enum rtr_object_kind { RTR_OBJ_SPHERE = 0, RTR_OBJ_MESH = 1, RTR_OBJ_VOLUME = 2 } rtr_object_kind;
 typedef enum rtr_background_kind { RTR_BG_UNIFORM = 0, RTR_BG_GRADIENT = 1, RTR_BG_SKYMAP = 2 } rtr_background_kind;
 /* RenderMode, lib/core/scene.rs:14-20 */
 typedef enum rtr_render_mode { RTR_MODE_FULL = 0, RTR_MODE_CLAY = 1, RTR_MODE_RANDOM = 2, RTR_MODE_NORMAL = 3 } rtr_render_mode;
@@ -92,6 +92,14 @@ typedef struct rtr_mesh {
     uint32_t reserved;
 } rtr_mesh;
 
+/* Volume, lib/volume.rs:19-32: a constant-density medium inside a boundary object.  The GPU path accepts
+ * sphere boundaries (the boundary's material is the medium's, normally Isotropic); a mesh boundary is
+ * RTR_ERR_UNSUPPORTED.  The boundary sphere is NOT listed in objects[] itself. */
+typedef struct rtr_volume {
+    rtr_sphere boundary;
+    float neg_inv_density; /* -1/density, as Volume::new stores it (volume.rs:29) */
+} rtr_volume;
+
 typedef struct rtr_material {
     uint32_t kind; /* rtr_material_kind */
     float rgb[3];
@@ -103,7 +111,7 @@ typedef struct rtr_material {
 /* Scene.objects is heterogeneous and ordered (scene.rs:37); order decides BVH ties and the linear scan */
 typedef struct rtr_object {
     uint32_t kind;  /* rtr_object_kind */
-    uint32_t index; /* into spheres[] or meshes[] */
+    uint32_t index; /* into spheres[], meshes[] or volumes[] */
 } rtr_object;
 
 /* lib/backgrounds.rs */
@@ -126,6 +134,8 @@ typedef struct rtr_scene_desc {
     const rtr_material *materials;
     uint32_t n_materials;
     rtr_background background;
+    const rtr_volume *volumes; /* appended in ABI revision 2 */
+    uint32_t n_volumes;
 } rtr_scene_desc;
 
 /* Camera, lib/core/camera.rs:27-34 */

@@ -63,6 +63,8 @@ def lib():
         L.or_probe_acos.restype = C.c_float
         L.or_probe_atan2.argtypes = [C.c_float, C.c_float, C.c_int]
         L.or_probe_atan2.restype = C.c_float
+        L.or_probe_log.argtypes = [C.c_float, C.c_int]
+        L.or_probe_log.restype = C.c_float
         L.or_last_error.restype = C.c_char_p
         _lib = L
     return _lib
@@ -119,6 +121,10 @@ class OracleScene:
                                           o.normals.ctypes.data_as(C.c_void_p), o.positions.shape[0],
                                           o.indices.ctypes.data_as(C.c_void_p), o.n_tris,
                                           remap.get(o.material, o.material)))
+            elif isinstance(o, S.Volume):
+                b = o.boundary
+                self._check(L.or_add_volume_sphere(self._s, f3(b.center), float(np.float32(b.radius)),
+                                                   remap.get(b.material, b.material), float(np.float32(o.density))))
             else:
                 raise TypeError(o)
 

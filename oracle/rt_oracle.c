@@ -400,8 +400,9 @@ static int bvh_hit(const bvh_node *n, const ray_t *ray, float tmin, float tmax, 
     return 0;
 }
 
+static inline float or_log(float x, int mode);
 /* lib/volume.rs:34-73  Volume::hit (boundary restricted to a sphere here) */
-static int volume_hit(const volume_t *v, const ray_t *ray, float tmin, float tmax, hit_t *out, tctx_t *tc) {
+static int volume_hit(const volume_t *v, const ray_t *ray, float tmin, float tmax, hit_t *out, tctx_t *tc, int trig_mode) {
     hit_t hit1, hit2;
     if (!sphere_hit(&v->boundary, ray, -INFINITY, INFINITY, &hit1, tc)) return 0;
     if (!sphere_hit(&v->boundary, ray, hit1.t + tmin, INFINITY, &hit2, tc)) return 0;
@@ -412,7 +413,7 @@ static int volume_hit(const volume_t *v, const ray_t *ray, float tmin, float tma
     float ray_length = v3_mag(ray->direction);
     float distance_inside_boundary = (hit2.t - hit1.t) * ray_length;
     float random_float = or_rng_unit_inclusive(&tc->rng); /* gen_range(0.0..=1.0) */
-    float hit_distance = v->neg_inv_density * logf(random_float);
+    float hit_distance = v->neg_inv_density * or_log(random_float, trig_mode);
     if (hit_distance > distance_inside_boundary) return 0;
     float t = hit1.t + hit_distance / ray_length;
     *out = hit_new(ray_at(ray, t), v3_new(1.0f, 0.0f, 0.0f), t, ray, v->boundary.material);
@@ -421,14 +422,13 @@ static int volume_hit(const volume_t *v, const ray_t *ray, float tmin, float tma
 
 static int object_hit(const or_scene *sc, const object_t *o, const ray_t *ray, float tmin, float tmax, hit_t *out,
                       tctx_t *tc) {
-    (void)sc;
     switch (o->kind) {
     case OBJ_SPHERE: return sphere_hit(&o->sphere, ray, tmin, tmax, out, tc);
     case OBJ_MESH: { /* mesh.rs:124-127 */
         collection c = {NULL, o->mesh};
         return bvh_hit(o->mesh->bvh_root, ray, tmin, tmax, &c, out, tc);
     }
-    default: return volume_hit(&o->volume, ray, tmin, tmax, out, tc);
+    default: return volume_hit(&o->volume, ray, tmin, tmax, out, tc, sc->trig_mode);
     }
 }
 
@@ -516,6 +516,37 @@ static float poly_atan2(float y, float x) {
     if (x < 0.0f) r = OR_PI - r;
     return y < 0.0f ? -r : r;
 }
+/* cephes-style logf, the sequence the HIP kernels use for Volume::hit's ln (volume.rs:58) */
+static float poly_log(float xx) {
+    if (!(xx > 0.0f)) return xx == 0.0f ? -INFINITY : NAN;
+    if (xx == INFINITY) return xx;
+    uint32_t b;
+    memcpy(&b, &xx, 4);
+    int e = (int)((b >> 23) & 0xffu) - 126;
+    if (((b >> 23) & 0xffu) == 0u) return logf(xx); /* denormal: never produced by the 23-bit uniform */
+    b = (b & 0x007fffffu) | 0x3f000000u;
+    float x;
+    memcpy(&x, &b, 4); /* frexp mantissa in [0.5, 1) */
+    if (x < 0.707106781186547524f) { e -= 1; x = x + x - 1.0f; } else { x = x - 1.0f; }
+    float z = x * x;
+    float y = 7.0376836292E-2f;
+    y = y * x - 1.1514610310E-1f;
+    y = y * x + 1.1676998740E-1f;
+    y = y * x - 1.2420140846E-1f;
+    y = y * x + 1.4249322787E-1f;
+    y = y * x - 1.6668057665E-1f;
+    y = y * x + 2.0000714765E-1f;
+    y = y * x - 2.4999993993E-1f;
+    y = y * x + 3.3333331174E-1f;
+    y = (y * x) * z;
+    float fe = (float)e;
+    if (e) y += -2.12194440e-4f * fe;
+    y += -0.5f * z;
+    z = x + y;
+    if (e) z += 0.693359375f * fe;
+    return z;
+}
+static inline float or_log(float x, int mode) { return mode == OR_TRIG_POLY ? poly_log(x) : logf(x); }
 static inline float or_acos(float x, int mode) { return mode == OR_TRIG_POLY ? poly_acos(x) : acosf(x); }
 static inline float or_atan2(float y, float x, int mode) { return mode == OR_TRIG_POLY ? poly_atan2(y, x) : atan2f(y, x); }
 
@@ -974,3 +1005,4 @@ void or_probe_rng(uint64_t seed, uint32_t pixel, uint32_t sample, int kind, floa
 }
 float or_probe_acos(float x, int trig_mode) { return or_acos(x, trig_mode); }
 float or_probe_atan2(float y, float x, int trig_mode) { return or_atan2(y, x, trig_mode); }
+float or_probe_log(float x, int trig_mode) { return or_log(x, trig_mode); }

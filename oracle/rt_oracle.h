@@ -37,8 +37,8 @@ enum {
 /* lib/core/scene.rs:14-20 */
 enum { OR_MODE_FULL = 0, OR_MODE_CLAY = 1, OR_MODE_RANDOM = 2, OR_MODE_NORMAL = 3 };
 
-/* trig used by SkyMap::sample: 0 = host libm (what Rust's f32::acos/atan2 call),
- * 1 = the polynomial acos/atan2 the HIP kernels use (DESIGN.md "transcendentals") */
+/* transcendentals (SkyMap::sample's acos/atan2, Volume::hit's ln): 0 = host libm (what Rust's f32 methods call),
+ * 1 = the polynomial forms the HIP kernels use (DESIGN.md "transcendentals") */
 enum { OR_TRIG_LIBM = 0, OR_TRIG_POLY = 1 };
 
 typedef struct or_scene or_scene;
@@ -109,6 +109,7 @@ int or_probe_mesh_leaf_order(or_scene *s, int object, uint32_t *out, int cap);
 void or_probe_rng(uint64_t seed, uint32_t pixel, uint32_t sample, int kind, float *out, int n);
 float or_probe_acos(float x, int trig_mode);
 float or_probe_atan2(float y, float x, int trig_mode);
+float or_probe_log(float x, int trig_mode);
 const char *or_last_error(void);
 
 #ifdef __cplusplus

@@ -3,12 +3,12 @@
 (csrc/, C ABI in include/rtr_hip.h); this package is the host-side mirror of the reference's scene API."""
 from .scene import (Camera, Dielectric, Emission, GradientBackground, Isotropic, Lambertian, MaterialHandle, Mesh,
                     Metal, MixMaterial, ObjectHandle, RenderMode, RenderSettings, Scene, SkyMap, Sphere,
-                    UniformBackground, load_obj)
+                    UniformBackground, Volume, load_obj)
 from .render import DEFAULT_SEED, Renderer, RenderTarget, render
 from ._capi import RtrError
 
 __all__ = [
     "Camera", "Dielectric", "Emission", "GradientBackground", "Isotropic", "Lambertian", "MaterialHandle", "Mesh",
     "Metal", "MixMaterial", "ObjectHandle", "RenderMode", "RenderSettings", "Scene", "SkyMap", "Sphere",
-    "UniformBackground", "load_obj", "DEFAULT_SEED", "Renderer", "RenderTarget", "render", "RtrError",
+    "UniformBackground", "Volume", "load_obj", "DEFAULT_SEED", "Renderer", "RenderTarget", "render", "RtrError",
 ]

@@ -20,6 +20,10 @@ class rtr_mesh(C.Structure):
                 ("material", C.c_uint32), ("reserved", C.c_uint32)]
 
 
+class rtr_volume(C.Structure):
+    _fields_ = [("boundary", rtr_sphere), ("neg_inv_density", C.c_float)]
+
+
 class rtr_material(C.Structure):
     _fields_ = [("kind", C.c_uint32), ("rgb", c_float3), ("param", C.c_float), ("first", C.c_uint32),
                 ("second", C.c_uint32)]
@@ -39,7 +43,8 @@ class rtr_scene_desc(C.Structure):
                 ("spheres", C.POINTER(rtr_sphere)), ("n_spheres", C.c_uint32),
                 ("meshes", C.POINTER(rtr_mesh)), ("n_meshes", C.c_uint32),
                 ("materials", C.POINTER(rtr_material)), ("n_materials", C.c_uint32),
-                ("background", rtr_background)]
+                ("background", rtr_background),
+                ("volumes", C.POINTER(rtr_volume)), ("n_volumes", C.c_uint32)]
 
 
 class rtr_camera(C.Structure):

@@ -23,14 +23,18 @@ namespace rtr {
 
 constexpr uint32_t REF_NONE = 0xFFFFFFFFu;  // BvhNode::None
 constexpr uint32_t REF_LEAF = 0x80000000u;  // BvhNode::Object
-constexpr uint32_t REF_TRI = 0x40000000u;   // leaf is a triangle (else sphere)
-constexpr uint32_t REF_INDEX = 0x3FFFFFFFu; // leaf rank L, or node index
+constexpr uint32_t REF_TRI = 0x40000000u;   // leaf is a triangle
+constexpr uint32_t REF_VOL = 0x20000000u;   // leaf is a Volume (lib/volume.rs); neither bit: sphere
+constexpr uint32_t REF_INDEX = 0x1FFFFFFFu; // leaf rank L, or node index
+
+constexpr uint32_t NODE_LVOL = 1u; // the left / right subtree holds a Volume leaf: Volume::hit draws a random
+constexpr uint32_t NODE_RVOL = 2u; // number on every visit, so such subtrees are never culled nor reordered
 
 struct alignas(16) DevNode {
     float lmin[3], lmax[3];
     float rmin[3], rmax[3];
     uint32_t lref, rref;
-    uint32_t pad0, pad1;
+    uint32_t flags, pad1;
 };
 static_assert(sizeof(DevNode) == 64, "node is one 64-byte gather");
 

@@ -184,7 +184,7 @@ RTR_DEV bool slab(const float *bmin, const float *bmax, const Ray &r, V3 inv, fl
 }
 
 // objects.rs:22-51 root selection.  a = |d|^2.  Returns true with t when a root lies in [tmin, tmax].
-RTR_DEV bool sphere_t(V3 c, float r2, const Ray &r, float a, float tmax, float &t) {
+RTR_DEV bool sphere_range(V3 c, float r2, const Ray &r, float a, float tmin, float tmax, float &t) {
     V3 oc = sub(r.o, c);
     float half_b = dot(oc, r.d);
     float cc = dot(oc, oc) - r2;
@@ -196,11 +196,62 @@ RTR_DEV bool sphere_t(V3 c, float r2, const Ray &r, float a, float tmax, float &
     // beyond tmax the second (>= the first: sq >= 0, a >= 0) is too, so its division is skipped; a NaN root
     // fails both comparisons and is accepted, exactly as in the reference.
     if (tmax < root) return false;
-    if (root < kTMin) {
+    if (root < tmin) {
         root = (-half_b + sq) / a;
-        if (root < kTMin || tmax < root) return false;
+        if (root < tmin || tmax < root) return false;
     }
     t = root;
+    return true;
+}
+// Sphere::hit as trace_ray reaches it: tmin = 0.00001 (render.rs:38)
+RTR_DEV bool sphere_t(V3 c, float r2, const Ray &r, float a, float tmax, float &t) {
+    return sphere_range(c, r2, r, a, kTMin, tmax, t);
+}
+
+// cephes-style logf (restated identically in the oracle's OR_TRIG_POLY mode) for Volume::hit's ln (volume.rs:58)
+RTR_DEV float poly_log(float xx) {
+    if (!(xx > 0.0f)) return xx == 0.0f ? -__builtin_inff() : __builtin_nanf("");
+    if (xx == __builtin_inff()) return xx;
+    uint32_t b = __float_as_uint(xx);
+    int e = (int)((b >> 23) & 0xffu) - 126;
+    if (((b >> 23) & 0xffu) == 0u) return logf(xx); // denormal: never produced by the 23-bit uniform
+    float x = __uint_as_float((b & 0x007fffffu) | 0x3f000000u); // frexp mantissa in [0.5, 1)
+    if (x < 0.707106781186547524f) { e -= 1; x = x + x - 1.0f; } else { x = x - 1.0f; }
+    float z = x * x;
+    float y = 7.0376836292E-2f;
+    y = y * x - 1.1514610310E-1f;
+    y = y * x + 1.1676998740E-1f;
+    y = y * x - 1.2420140846E-1f;
+    y = y * x + 1.4249322787E-1f;
+    y = y * x - 1.6668057665E-1f;
+    y = y * x + 2.0000714765E-1f;
+    y = y * x - 2.4999993993E-1f;
+    y = y * x + 3.3333331174E-1f;
+    y = (y * x) * z;
+    const float fe = (float)e;
+    if (e) y += -2.12194440e-4f * fe;
+    y += -0.5f * z;
+    z = x + y;
+    if (e) z += 0.693359375f * fe;
+    return z;
+}
+
+// Volume::hit (lib/volume.rs:34-73) over a sphere boundary.  Draws one random number per call -- after both
+// boundary hits succeeded and the clipped interval is non-empty -- exactly where the reference draws it.
+RTR_DEV bool volume_t(V3 c, float r2, float neg_inv_density, const Ray &r, float a, float tmax, Rng &rng, float &t) {
+    float t1, t2;
+    if (!sphere_range(c, r2, r, a, -__builtin_inff(), __builtin_inff(), t1)) return false;
+    if (!sphere_range(c, r2, r, a, t1 + kTMin, __builtin_inff(), t2)) return false;
+    if (t1 < kTMin) t1 = kTMin;
+    if (t2 > tmax) t2 = tmax;
+    if (t1 >= t2) return false;
+    if (t1 < 0.0f) t1 = 0.0f;
+    const float ray_length = rt_sqrt(a); // ray.direction.magnitude()
+    const float distance_inside_boundary = (t2 - t1) * ray_length;
+    const float random_float = rng_unit_inclusive(rng); // gen_range(0.0..=1.0), volume.rs:57
+    const float hit_distance = neg_inv_density * poly_log(random_float);
+    if (hit_distance > distance_inside_boundary) return false;
+    t = t1 + hit_distance / ray_length;
     return true;
 }
 
@@ -233,7 +284,7 @@ RTR_DEV bool accept_tree(const Best &b, float t, uint32_t leaf) {
     return b.leaf == REF_NONE || t < b.t || (t == b.t && (leaf & REF_INDEX) > (b.leaf & REF_INDEX));
 }
 
-RTR_DEV void test_leaf(const RenderParams &p, uint32_t ref, const Ray &r, float a, Best &best) {
+RTR_DEV void test_leaf(const RenderParams &p, uint32_t ref, const Ray &r, float a, Best &best, Rng &rng) {
     const float4 *hot = reinterpret_cast<const float4 *>(p.leaf_hot + (ref & REF_INDEX));
     float4 q0 = hot[0], q1 = hot[1], q2 = hot[2];
     if (ref & REF_TRI) {
@@ -241,6 +292,12 @@ RTR_DEV void test_leaf(const RenderParams &p, uint32_t ref, const Ray &r, float 
         if (triangle_t(mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y), mk(q1.z, q1.w, q2.x), r, t, u, v) &&
             accept_tree(best, t, ref)) {
             best.t = t; best.u = u; best.v = v; best.leaf = ref;
+        }
+    } else if (ref & REF_VOL) {
+        float t;
+        // Volume::hit(ray, tmin, +inf) as called from the tree (bvh.rs:156)
+        if (volume_t(mk(q0.x, q0.y, q0.z), q1.x, q1.y, r, a, __builtin_inff(), rng, t) && accept_tree(best, t, ref)) {
+            best.t = t; best.leaf = ref;
         }
     } else {
         float t;
@@ -258,7 +315,9 @@ RTR_DEV void test_leaf(const RenderParams &p, uint32_t ref, const Ray &r, float 
 // tmax_box is the tmax the reference hands to AABB::hit: +inf from the scene tree, closest_so_far when a
 // mesh is reached from the linear world (scene.rs:147, mesh.rs:124-127).
 RTR_DEV void traverse(const RenderParams &p, uint32_t root, const Ray &r, V3 inv, float a, float tmax_box,
-                      Best &best, uint32_t *stk_ref, float *stk_t, uint32_t lane) {
+                      Best &best, uint32_t *stk_ref, float *stk_t, uint32_t lane, Rng &rng) {
+    // Volume leaves draw a random number on every visit (volume.rs:57), so a subtree that holds one is visited
+    // exactly when, and in the order, the reference visits it: never culled by the best hit, left before right.
     uint32_t sp = 0;
     uint32_t cur = root;
     for (;;) {
@@ -266,7 +325,7 @@ RTR_DEV void traverse(const RenderParams &p, uint32_t root, const Ray &r, V3 inv
         if (cur == REF_NONE) {
             pop = true;
         } else if (cur & REF_LEAF) {
-            test_leaf(p, cur, r, a, best);
+            test_leaf(p, cur, r, a, best, rng);
             pop = true;
         } else {
             const float4 *nq = reinterpret_cast<const float4 *>(p.nodes + cur);
@@ -274,20 +333,24 @@ RTR_DEV void traverse(const RenderParams &p, uint32_t root, const Ray &r, V3 inv
             float lmin[3] = {q0.x, q0.y, q0.z}, lmax[3] = {q0.w, q1.x, q1.y};
             float rmin[3] = {q1.z, q1.w, q2.x}, rmax[3] = {q2.y, q2.z, q2.w};
             uint32_t l = __float_as_uint(q3.x), rr = __float_as_uint(q3.y);
+            const uint32_t flags = __float_as_uint(q3.z);
+            const bool lvol = flags & NODE_LVOL, rvol = flags & NODE_RVOL;
             bool hl = l != REF_NONE, hr = rr != REF_NONE;
             float el = 0.0f, er = 0.0f;
             if (hl && !(l & REF_LEAF)) {
                 hl = slab(lmin, lmax, r, inv, tmax_box, el);
-                if (best.leaf != REF_NONE && el > best.t) hl = false;
+                if (!lvol && best.leaf != REF_NONE && el > best.t) hl = false;
             }
             if (hr && !(rr & REF_LEAF)) {
                 hr = slab(rmin, rmax, r, inv, tmax_box, er);
-                if (best.leaf != REF_NONE && er > best.t) hr = false;
+                if (!rvol && best.leaf != REF_NONE && er > best.t) hr = false;
             }
             if (hl && hr) {
                 bool sw = er < el;
+                if (lvol && rvol) sw = false; // both subtrees draw: keep the reference's left-then-right order
                 uint32_t second = sw ? l : rr;
                 float esecond = sw ? el : er;
+                if (sw ? lvol : rvol) esecond = -__builtin_inff(); // never culled at pop time
                 cur = sw ? rr : l;
                 if (sp < p.stack_cap) {
                     stk_ref[sp * 64 + lane] = second;
@@ -351,6 +414,8 @@ RTR_DEV void finish_leaf(const RenderParams &p, const Best &best, const Ray &r, 
         bool use_face = (mag > 0.0f) || (mag == 0.0f && (dd < 0.0f || (dd == 0.0f && __builtin_signbit(dd))));
         if (use_face) n = fn;
         face_forward(h, r, n);
+    } else if (best.leaf & REF_VOL) {
+        face_forward(h, r, mk(1.0f, 0.0f, 0.0f)); // volume.rs:67: the arbitrary constant normal
     } else {
         const float4 *hot = reinterpret_cast<const float4 *>(p.leaf_hot + L);
         float4 q0 = hot[0];
@@ -369,7 +434,7 @@ struct SphereRegs {
 // world.hit (render.rs:38).  Returns false on miss.
 template <uint32_t WORLD, uint32_t NS>
 RTR_DEV bool world_hit(const RenderParams &p, const Ray &r, Hit &h, uint32_t *stk_ref, float *stk_t, uint32_t lane,
-                       const SphereRegs<NS> &sr, const uint32_t *lds_spheres) {
+                       const SphereRegs<NS> &sr, const uint32_t *lds_spheres, Rng &rng) {
     const float a = dot(r.d, r.d); // objects.rs:25, hoisted per ray
     if constexpr (WORLD == WORLD_LINEAR_SPHERES && NS > 0) {
         // scene.rs:141-157, fully unrolled over scalar-register sphere constants.  (A two-pass variant -- candidate
@@ -422,7 +487,7 @@ RTR_DEV bool world_hit(const RenderParams &p, const Ray &r, Hit &h, uint32_t *st
                 float e;
                 go = slab(p.root_box, p.root_box + 3, r, inv, __builtin_inff(), e);
             }
-            if (go) traverse(p, root, r, inv, a, __builtin_inff(), best, stk_ref, stk_t, lane);
+            if (go) traverse(p, root, r, inv, a, __builtin_inff(), best, stk_ref, stk_t, lane, rng);
         } else {
             // scene.rs:141-157 with meshes: object.hit(ray, tmin, closest_so_far); a mesh returns the nearest
             // triangle of the boxes that pass AABB::hit(.., closest_so_far) and Triangle::hit ignores tmax
@@ -436,7 +501,9 @@ RTR_DEV bool world_hit(const RenderParams &p, const Ray &r, Hit &h, uint32_t *st
                     const float4 *hot = reinterpret_cast<const float4 *>(p.leaf_hot + (ref & REF_INDEX));
                     float4 q0 = hot[0], q1 = hot[1];
                     float t;
-                    if (sphere_t(mk(q0.x, q0.y, q0.z), q1.x, r, a, closest, t)) {
+                    const bool got = (ref & REF_VOL) ? volume_t(mk(q0.x, q0.y, q0.z), q1.x, q1.y, r, a, closest, rng, t)
+                                                     : sphere_t(mk(q0.x, q0.y, q0.z), q1.x, r, a, closest, t);
+                    if (got) {
                         closest = t; best.t = t; best.leaf = ref;
                     }
                 } else {
@@ -447,7 +514,7 @@ RTR_DEV bool world_hit(const RenderParams &p, const Ray &r, Hit &h, uint32_t *st
                         float e;
                         go = slab(o.box, o.box + 3, r, inv, closest, e);
                     }
-                    if (go) traverse(p, ref, r, inv, a, closest, local, stk_ref, stk_t, lane);
+                    if (go) traverse(p, ref, r, inv, a, closest, local, stk_ref, stk_t, lane, rng);
                     if (local.leaf != REF_NONE) {
                         closest = local.t;
                         best = local;
@@ -613,7 +680,7 @@ __global__ __launch_bounds__(64, RTR_X_WAVES_PER_EU) void k_render(const RenderP
 #endif
         bool done;
         V3 term;
-        const bool was_hit = world_hit<WORLD, NS>(p, ray, h, stk_ref, stk_t, lane, sr, lds_spheres);
+        const bool was_hit = world_hit<WORLD, NS>(p, ray, h, stk_ref, stk_t, lane, sr, lds_spheres, rng);
         RTR_STAMP(0)
         if (!was_hit) {
             term = background(p, ray);

@@ -151,7 +151,24 @@ struct Flattener {
         uint32_t ref;
         Box box;
         uint32_t height;
+        bool has_volume = false; // the subtree holds a Volume leaf
     };
+
+    // Volume (lib/volume.rs:19-32) over a sphere boundary: hot = boundary centre, radius, radius^2, -1/density
+    Emitted emit_volume(uint32_t object, const rtr_volume &v) {
+        uint32_t L = (uint32_t)out.leaf_hot.size();
+        DevLeafHot hot{};
+        const rtr_sphere &s = v.boundary;
+        hot.f[0] = s.center[0]; hot.f[1] = s.center[1]; hot.f[2] = s.center[2]; hot.f[3] = s.radius;
+        hot.f[4] = s.radius * s.radius;
+        hot.f[5] = v.neg_inv_density;
+        DevLeafCold cold{};
+        cold.material = s.material; cold.object = object; cold.handle = 0; // Object::material = boundary.material(), volume.rs:98-100
+        out.leaf_hot.push_back(hot);
+        out.leaf_cold.push_back(cold);
+        out.has_volumes = true;
+        return {REF_LEAF | REF_VOL | L, Box{}, 0, true};
+    }
 
     Emitted emit_sphere(uint32_t object, const rtr_sphere &s) {
         uint32_t L = (uint32_t)out.leaf_hot.size();
@@ -189,6 +206,8 @@ struct Flattener {
         Emitted e;
         if (o.kind == RTR_OBJ_SPHERE) {
             e = emit_sphere(object, desc.spheres[o.index]);
+        } else if (o.kind == RTR_OBJ_VOLUME) {
+            e = emit_volume(object, desc.volumes[o.index]);
         } else {
             const MeshBuild &mb = meshes[o.index];
             e = emit_mesh_node(object, mb, mb.tree.root); // Mesh::hit = bvh_root.hit, mesh.rs:124-127
@@ -208,7 +227,7 @@ struct Flattener {
         Emitted l = emit_scene_node(n.left);
         Emitted r = emit_scene_node(n.right);
         fill_node(idx, l, r);
-        return {idx, n.box, 1 + std::max(l.height, r.height)};
+        return {idx, n.box, 1 + std::max(l.height, r.height), l.has_volume || r.has_volume};
     }
 
     void fill_node(uint32_t idx, const Emitted &l, const Emitted &r) {
@@ -220,6 +239,7 @@ struct Flattener {
         }
         d.lref = l.ref;
         d.rref = r.ref;
+        d.flags = (l.has_volume ? NODE_LVOL : 0u) | (r.has_volume ? NODE_RVOL : 0u);
     }
 };
 
@@ -228,7 +248,7 @@ struct Flattener {
 int build_flat_scene(const rtr_scene_desc &desc, FlatScene &out, std::string &err) {
     out = FlatScene{};
     if ((desc.n_objects && !desc.objects) || (desc.n_spheres && !desc.spheres) || (desc.n_meshes && !desc.meshes) ||
-        (desc.n_materials && !desc.materials)) {
+        (desc.n_materials && !desc.materials) || (desc.n_volumes && !desc.volumes)) {
         err = "null array with non-zero count in rtr_scene_desc";
         return RTR_ERR_INVALID_ARGUMENT;
     }
@@ -330,6 +350,15 @@ int build_flat_scene(const rtr_scene_desc &desc, FlatScene &out, std::string &er
                 ob[i].mn[k] = s.center[k] - s.radius;
                 ob[i].mx[k] = s.center[k] + s.radius;
             }
+        } else if (o.kind == RTR_OBJ_VOLUME) {
+            if (o.index >= desc.n_volumes) { err = "volume index out of bounds"; return RTR_ERR_BAD_INDEX; }
+            const rtr_sphere &s = desc.volumes[o.index].boundary;
+            if (s.material >= desc.n_materials) { err = "volume material out of bounds"; return RTR_ERR_BAD_INDEX; }
+            for (int k = 0; k < 3; k++) { // Bounded for Volume = boundary.bounds(), volume.rs:90-94
+                ob[i].mn[k] = s.center[k] - s.radius;
+                ob[i].mx[k] = s.center[k] + s.radius;
+            }
+            out.spheres_only = false;
         } else if (o.kind == RTR_OBJ_MESH) {
             if (o.index >= desc.n_meshes) { err = "mesh index out of bounds"; return RTR_ERR_BAD_INDEX; }
             ob[i] = meshes[o.index].bounds; // Bounded for Mesh, mesh.rs:234-238

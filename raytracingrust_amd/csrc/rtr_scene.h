@@ -29,6 +29,7 @@ struct FlatScene {
     uint32_t tree_height = 0;   // Split nodes on the longest root-to-leaf path of the scene tree
     uint32_t mesh_height = 0;   // same, over the mesh subtrees alone (linear world with meshes)
     bool spheres_only = true;
+    bool has_volumes = false;   // a Volume leaf exists: traversal must keep the reference's visit set and order
     uint32_t n_objects = 0, n_spheres = 0, n_meshes = 0, n_triangles = 0;
 };
 

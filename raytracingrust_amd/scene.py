@@ -6,7 +6,7 @@
     Mesh (from_file / from_buffers)          lib/core/mesh.rs:62-117
     Lambertian, Metal, Emission, Dielectric,
     MixMaterial                              lib/materials.rs
-    Isotropic                                lib/volume.rs:75-88
+    Volume, Isotropic                        lib/volume.rs:19-32,75-88
     UniformBackground, GradientBackground,
     SkyMap                                   lib/backgrounds.rs
 
@@ -160,6 +160,26 @@ class Sphere:
         self.material = _mh(material)
 
 
+class Volume:
+    """lib/volume.rs:19-32: a constant-density medium inside a boundary object (`Volume::new(boundary, density)`
+    stores -1/density).  The GPU path takes a Sphere boundary; its material (normally Isotropic) is the medium's."""
+
+    def __init__(self, boundary: "Sphere", density: float):
+        if not isinstance(boundary, Sphere):
+            raise TypeError("Volume boundaries other than Sphere are outside the GPU path")
+        self.boundary = boundary
+        self.density = float(f32(density))
+
+    @property
+    def neg_inv_density(self) -> float:
+        stored = getattr(self, "_neg_inv_density", None)
+        return stored if stored is not None else float(f32(-1.0) / f32(self.density))  # volume.rs:29
+
+    @property
+    def material(self) -> int:
+        return self.boundary.material  # Object::material = boundary.material(), volume.rs:98-100
+
+
 def load_obj(path: str) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
     """The subset of obj-rs 0.7 `load_obj::<obj::Vertex, u32>` the reference relies on (mesh.rs:63-66):
     triangulated faces with normals (`v//vn` or `v/vt/vn`); one output vertex per distinct
@@ -291,7 +311,7 @@ class Scene:
         self.camera = camera if camera is not None else Camera()
         self.settings = settings if settings is not None else RenderSettings()
         self.background = background if background is not None else UniformBackground([0.8, 0.8, 0.8])
-        self.objects: List[Union[Sphere, Mesh]] = []
+        self.objects: List[Union[Sphere, Mesh, Volume]] = []
         self.materials: List[Material] = []
 
     @classmethod
@@ -342,8 +362,16 @@ class Scene:
                 scene.add_object(Sphere(_xyz(o["center"]), o["radius"], int(o["material"])))
             elif t == "Mesh":
                 raise ValueError("Mesh cannot be deserialized (the reference panics: mesh.rs:51-60)")
+            elif t == "Volume":
+                b = o["boundary"]
+                if b.get("type") != "Sphere":
+                    raise ValueError("Volume boundaries other than Sphere are outside the GPU path")
+                vol = Volume(Sphere(_xyz(b["center"]), b["radius"], int(b["material"])), 1.0)
+                vol.density = float(f32(-1.0) / f32(o["neg_inv_density"]))
+                vol._neg_inv_density = float(f32(o["neg_inv_density"]))  # keep the stored value bit for bit
+                scene.add_object(vol)
             else:
-                raise ValueError(f"object type {t!r} is outside the GPU path (Volume: SURVEY.md section 8f N3)")
+                raise ValueError(f"unknown object type {t!r}")
         return scene
 
     @staticmethod
@@ -418,8 +446,11 @@ class LoweredScene:
         self._keep = []
         spheres = [o for o in scene.objects if isinstance(o, Sphere)]
         meshes = [o for o in scene.objects if isinstance(o, Mesh)]
-        if len(spheres) + len(meshes) != len(scene.objects):
-            raise TypeError("Scene.objects may hold Sphere and Mesh only")
+        volumes = [o for o in scene.objects if isinstance(o, Volume)]
+        if len(spheres) + len(meshes) + len(volumes) != len(scene.objects):
+            raise TypeError("Scene.objects may hold Sphere, Mesh and Volume only")
+        vol = (_capi.rtr_volume * max(len(volumes), 1))()
+        vi = 0
         n_obj = len(scene.objects)
         objs = (_capi.rtr_object * max(n_obj, 1))()
         sph = (_capi.rtr_sphere * max(len(spheres), 1))()
@@ -432,6 +463,14 @@ class LoweredScene:
                 sph[si].radius = o.radius
                 sph[si].material = o.material
                 si += 1
+            elif isinstance(o, Volume):
+                objs[i].kind, objs[i].index = 2, vi
+                b = o.boundary
+                vol[vi].boundary.center = _capi.c_float3(*[float(x) for x in b.center])
+                vol[vi].boundary.radius = b.radius
+                vol[vi].boundary.material = b.material
+                vol[vi].neg_inv_density = o.neg_inv_density
+                vi += 1
             else:
                 objs[i].kind, objs[i].index = 1, mi
                 self._keep += [o.positions, o.normals, o.indices]
@@ -454,6 +493,7 @@ class LoweredScene:
         d.spheres, d.n_spheres = sph, len(spheres)
         d.meshes, d.n_meshes = msh, len(meshes)
         d.materials, d.n_materials = mats, len(lm)
+        d.volumes, d.n_volumes = vol, len(volumes)
         bg = scene.background
         if isinstance(bg, UniformBackground):
             d.background.kind = 0
@@ -469,7 +509,7 @@ class LoweredScene:
             d.background.width, d.background.height = bg.width, bg.height
         else:
             raise TypeError(f"not a background: {bg!r}")
-        self._keep += [objs, sph, msh, mats]
+        self._keep += [objs, sph, msh, mats, vol]
         self.desc = d
 
 

@@ -34,6 +34,22 @@ def _mix_scene():
     return s
 
 
+def _fog_scene():
+    s = rt.Scene()
+    s.settings.samples_per_pixel = 3
+    s.settings.max_ray_depth = 8
+    s.background = rt.GradientBackground([1.0, 1.0, 1.0], [0.5, 0.7, 1.0])
+    ground = s.add_material(rt.Lambertian([0.5, 0.5, 0.5]))
+    red = s.add_material(rt.Lambertian([0.8, 0.2, 0.2]))
+    fog = s.add_material(rt.Isotropic([1.0, 1.0, 1.0]))
+    smoke = s.add_material(rt.Isotropic([0.1, 0.1, 0.1]))
+    s.add_object(rt.Sphere([0.0, -100.5, -1.0], 100.0, ground))
+    s.add_object(rt.Sphere([0.6, 0.0, -1.2], 0.5, red))
+    s.add_object(rt.Volume(rt.Sphere([0.0, 0.0, 0.0], 30.0, fog), 0.08))
+    s.add_object(rt.Volume(rt.Sphere([-0.7, 0.2, -1.0], 0.45, smoke), 6.0))
+    return s
+
+
 CASES = {
     "benchmark_linear_64x36x4": (lambda: benchmark_scene(4), 64, 36, 0x5EED),
     "simple_bvh_48x48x2": (lambda: simple_scene(2), 48, 48, 17),
@@ -42,5 +58,6 @@ CASES = {
     "monkey_glass_sky_40x24x2": (lambda: monkey_scene(2, material=rt.Dielectric(1.5), background=_sky_small()), 40, 24, 20),
     "house_bvh_48x27x1": (lambda: house_scene(1), 48, 27, 21),
     "mix_linear_64x36x3": (_mix_scene, 64, 36, 22),
+    "fog_volumes_bvh_48x32x3": (_fog_scene, 48, 32, 24),
     "clay_mode_40x40x2": (lambda: simple_scene(2, mode=rt.RenderMode.Clay), 40, 40, 23),
 }

@@ -200,3 +200,36 @@ def test_frame_pipeline_over_rccl_single_rank(gpu_renderer):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def _fog_scene(bvh, spp=4, two_volumes=False):
+    """src/gui.rs:98-103 (commented-out there): a big Isotropic fog volume around the scene, plus solids."""
+    s = rt.Scene()
+    s.settings.samples_per_pixel = spp
+    s.settings.enable_bvh_tree = bvh
+    s.settings.max_ray_depth = 8
+    s.background = rt.GradientBackground([1.0, 1.0, 1.0], [0.5, 0.7, 1.0])
+    ground = s.add_material(rt.Lambertian([0.5, 0.5, 0.5]))
+    red = s.add_material(rt.Lambertian([0.8, 0.2, 0.2]))
+    glass = s.add_material(rt.Dielectric(1.5))
+    fog = s.add_material(rt.Isotropic([1.0, 1.0, 1.0]))
+    smoke = s.add_material(rt.Isotropic([0.1, 0.1, 0.1]))
+    s.add_object(rt.Sphere([0.0, -100.5, -1.0], 100.0, ground))
+    s.add_object(rt.Sphere([0.6, 0.0, -1.2], 0.5, red))
+    s.add_object(rt.Volume(rt.Sphere([0.0, 0.0, 0.0], 30.0, fog), 0.08))
+    s.add_object(rt.Sphere([-0.7, 0.0, -1.0], 0.5, glass))
+    if two_volumes:
+        s.add_object(rt.Volume(rt.Sphere([-0.7, 0.9, -1.0], 0.4, smoke), 4.0))
+        s.add_object(rt.Volume(rt.Sphere([0.2, 0.3, -0.6], 0.25, smoke), 9.0))
+    return s
+
+
+@pytest.mark.parametrize("bvh", [True, False])
+@pytest.mark.parametrize("two", [False, True])
+def test_volume_fog(gpu_renderer, bvh, two):
+    """Volume::hit (volume.rs:34-73) draws a random number INSIDE world.hit, once per visit: parity needs the GPU
+    traversal to visit Volume leaves exactly when and in the order the reference does (never culled, left first)."""
+    c, st, o_st = run_both(gpu_renderer, _fog_scene(bvh, two_volumes=two), 96, 64, 31)
+    assert st.segments == o_st.segments
+    assert c["mismatched_pixels"] == 0, c
+    assert c["max_u8_delta"] == 0
