@@ -27,7 +27,24 @@ sys.path.insert(0, ROOT)
 # algorithmic bytes per ray segment, SURVEY.md section 8(d): 96 (path state in+out) + 20 per sphere tested
 # + 32 per node + 48 per triangle (+12 per SkyMap texel); linear world of benchmark.json: 5 spheres, no nodes
 BYTES_PER_SEGMENT_C2 = 96 + 20 * 5
+# the other configurations: N_node / N_sph / N_tri / sky fraction per segment measured by the oracle under the
+# reference's unculled traversal (scripts/bench_configs.py prints them), folded into B_seg
+BYTES_PER_SEGMENT = {"c2": 196.0, "c1": 1032.6, "c2b": 317.5, "c3": 1240.7, "c3l": 937.2, "c4": 1480.6, "c5": 1038.4}
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
+
+
+def pmc_traffic(args, world):
+    """HBM-side bytes per launch of the headline kernel from the committed rocprofv3 PMC passes (profiles/): the
+    counters cannot be read inside this process, so the figure of the same command's profile run is reported."""
+    if args.pmc_traffic is not None:
+        return args.pmc_traffic
+    if world != 1 or args.config or (args.width, args.height, args.spp) != (1920, 1080, 256) or args.bvh:
+        return None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01", "traffic.json")) as fh:
+            return float(json.load(fh)["bytes_per_launch"])
+    except (OSError, KeyError, ValueError):
+        return None
 
 
 def parse_args():
@@ -175,7 +192,9 @@ def main():
         mrays = total_segments / elapsed / 1e6
         seg_per_launch = my_segments / max(args.steps, 1)  # rank 0's kernel (N=1: the whole frame)
         pixels_per_launch = stats.primary_samples / max(args.spp, 1)
-        alg_bytes = BYTES_PER_SEGMENT_C2 * seg_per_launch + 4.0 * pixels_per_launch
+        b_seg = BYTES_PER_SEGMENT.get(args.config, BYTES_PER_SEGMENT_C2) if args.config else (
+            BYTES_PER_SEGMENT["c2b"] if args.bvh else BYTES_PER_SEGMENT_C2)
+        alg_bytes = b_seg * seg_per_launch + 4.0 * pixels_per_launch
         achieved = alg_bytes / (my_kernel_ms * 1e-3) / 1e9 if my_kernel_ms > 0 else 0.0
         out = {
             "metric": "Mrays/s", "value": round(mrays, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps,
@@ -193,10 +212,14 @@ def main():
             },
             "roofline": {
                 "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": args.pmc_traffic,
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(args, world),
                 "kernel": "k_render<linear spheres>" if not scene.settings.enable_bvh_tree else "k_render<bvh>",
-                "algorithmic_bytes_per_launch": int(alg_bytes), "bytes_per_segment": BYTES_PER_SEGMENT_C2,
+                "algorithmic_bytes_per_launch": int(alg_bytes), "bytes_per_segment": b_seg,
                 "kernel_ms_hip_events": round(my_kernel_ms, 4),
+                "note": "algorithmic bytes are SURVEY 8(d)'s streaming-wavefront model (48 B of path state in and out "
+                        "per segment + geometry records); this kernel keeps path state in registers and the scene in "
+                        "SGPRs/LDS/L1, so measured HBM traffic is ~the framebuffer and frac can exceed 1: the kernel "
+                        "is VALU-issue bound (DESIGN.md section 5)",
             },
         }
         if not args.no_cpu_baseline and world == 1:
