@@ -33,18 +33,37 @@ BYTES_PER_SEGMENT = {"c2": 196.0, "c1": 1032.6, "c2b": 317.5, "c3": 1240.7, "c3l
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
 
 
-def pmc_traffic(args, world):
-    """HBM-side bytes per launch of the headline kernel from the committed rocprofv3 PMC passes (profiles/): the
-    counters cannot be read inside this process, so the figure of the same command's profile run is reported."""
-    if args.pmc_traffic is not None:
-        return args.pmc_traffic
+def committed_pmc(args, world):
+    """Counters of the headline kernel from the committed rocprofv3 PMC passes (profiles/r01/traffic.json): they
+    cannot be read inside this process, so the figures of the same command's profile run are reported."""
     if world != 1 or args.config or (args.width, args.height, args.spp) != (1920, 1080, 256) or args.bvh:
         return None
     try:
         with open(os.path.join(ROOT, "profiles", "r01", "traffic.json")) as fh:
-            return float(json.load(fh)["bytes_per_launch"])
-    except (OSError, KeyError, ValueError):
+            return json.load(fh)
+    except (OSError, ValueError):
         return None
+
+
+def pmc_traffic(args, world):
+    if args.pmc_traffic is not None:
+        return args.pmc_traffic
+    d = committed_pmc(args, world)
+    return float(d["bytes_per_launch"]) if d and "bytes_per_launch" in d else None
+
+
+def valu_issue(args, world, kernel_ms):
+    """The bound that actually binds: VALU issue.  One wave64 VALU instruction occupies a SIMD-32 for >= 2 cycles,
+    so the chip issues at most 1024 SIMDs x 2.4e9 / 2 wave-instructions per second (MI355X_MICROARCH.md)."""
+    d = committed_pmc(args, world)
+    if not d or "sq_insts_valu_per_launch" not in d or kernel_ms <= 0:
+        return None
+    peak = 1024 * 2.4e9 / 2.0
+    ach = float(d["sq_insts_valu_per_launch"]) / (kernel_ms * 1e-3)
+    return {"wave_insts_per_launch": float(d["sq_insts_valu_per_launch"]), "achieved_per_s": round(ach, 0),
+            "peak_per_s": peak, "frac": round(ach / peak, 4),
+            "source": "SQ_INSTS_VALU from profiles/r01 (same command), kernel time from this run's HIP events; "
+                      "half-rate (compare/select/int-mul) and quarter-rate (sqrt/rcp) instructions make 1.0 unreachable"}
 
 
 def parse_args():
@@ -216,6 +235,7 @@ def main():
                 "kernel": "k_render<linear spheres>" if not scene.settings.enable_bvh_tree else "k_render<bvh>",
                 "algorithmic_bytes_per_launch": int(alg_bytes), "bytes_per_segment": b_seg,
                 "kernel_ms_hip_events": round(my_kernel_ms, 4),
+                "valu_issue": valu_issue(args, world, my_kernel_ms),
                 "note": "algorithmic bytes are SURVEY 8(d)'s streaming-wavefront model (48 B of path state in and out "
                         "per segment + geometry records); this kernel keeps path state in registers and the scene in "
                         "SGPRs/LDS/L1, so measured HBM traffic is ~the framebuffer and frac can exceed 1: the kernel "

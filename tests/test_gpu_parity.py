@@ -233,3 +233,45 @@ def test_volume_fog(gpu_renderer, bvh, two):
     assert st.segments == o_st.segments
     assert c["mismatched_pixels"] == 0, c
     assert c["max_u8_delta"] == 0
+
+
+@pytest.mark.parametrize("w,h", [(1, 1), (1, 9), (9, 1), (2, 2), (8, 8), (9, 9)])
+def test_degenerate_target_sizes(gpu_renderer, w, h):
+    """render.rs:88-89 divides by (W-1) and (H-1): a 1-pixel-wide target makes u or v inf/NaN.  The reference does
+    not guard it; neither do we -- but the GPU must go wrong exactly like the oracle (NaN where it has NaN)."""
+    scene = benchmark_scene(3)
+    r = gpu_renderer
+    r.upload_scene(scene)
+    rgba, mean = r.render(w, h, seed=13, want_rgba8=True, want_mean=True)
+    st = r.stats()
+    o_rgba, o_mean, o_st = pyoracle.OracleScene(scene).render(w, h, 13, threads=0)
+    assert st.segments == o_st.segments
+    both_nan = np.isnan(mean) & np.isnan(o_mean)
+    same = (mean.view(np.uint32) == o_mean.view(np.uint32)) | both_nan
+    assert np.all(same), (mean, o_mean)
+    assert np.array_equal(rgba, o_rgba)
+
+
+def test_empty_scene_and_extreme_settings(gpu_renderer):
+    r = gpu_renderer
+    s = rt.Scene()  # no objects: BvhNode::None
+    s.settings.samples_per_pixel = 3
+    for bvh in (True, False):
+        s.settings.enable_bvh_tree = bvh
+        c, st, o_st = run_both(r, s, 24, 16, 1)
+        assert c["mismatched_pixels"] == 0 and st.segments == o_st.segments == 24 * 16 * 3
+    b = benchmark_scene(1, max_ray_depth=255)  # u8::MAX
+    c, st, o_st = run_both(r, b, 32, 24, 2)
+    assert c["mismatched_pixels"] == 0 and st.segments == o_st.segments
+    b = benchmark_scene(0)  # zero samples: 0/0 = NaN -> `as u8` = 0 (color.rs:34-41)
+    r.upload_scene(b)
+    rgba, mean = r.render(16, 8, seed=1, want_rgba8=True, want_mean=True)
+    assert np.all(np.isnan(mean)) and np.all(rgba[..., :3] == 0) and np.all(rgba[..., 3] == 255)
+    with pytest.raises(rt.RtrError):
+        r.render(0, 8)
+    bad = benchmark_scene(1, clamp_indirect=float("nan"))
+    with pytest.raises(rt.RtrError):
+        r.render(8, 8, scene=bad)
+    bad = benchmark_scene(1, max_ray_depth=256)
+    with pytest.raises(rt.RtrError):
+        r.render(8, 8, scene=bad)
