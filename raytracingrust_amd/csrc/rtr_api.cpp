@@ -133,6 +133,7 @@ int launch_frame(rtr_context *ctx, const rtr_camera *camera, const rtr_settings 
     else if (fs.spheres_only) { p.world = rtr::WORLD_LINEAR_SPHERES; p.stack_cap = 0u; }
     else { p.world = rtr::WORLD_LINEAR_GENERIC; p.stack_cap = fs.mesh_height + 1u; }
     p.n_objects = fs.n_objects;
+    p.has_volumes = fs.has_volumes ? 1u : 0u;
     p.root_ref = fs.root_ref;
     std::memcpy(p.root_box, fs.root_box, sizeof p.root_box);
     p.nodes = static_cast<const rtr::DevNode *>(ctx->d_nodes);

@@ -92,6 +92,7 @@ struct RenderParams {
     uint32_t stack_cap; // entries per lane
     uint32_t sphere_regs;   // linear sphere world: spheres held in scalar registers (0 = generic loop)
     uint32_t lds_materials; // number of material records staged in LDS (0 = read from HBM/L1)
+    uint32_t has_volumes;   // the scene holds Volume objects: kernels instantiated with the visit-order rules
     const DevNode *nodes;
     const DevLeafHot *leaf_hot;
     const DevLeafCold *leaf_cold;

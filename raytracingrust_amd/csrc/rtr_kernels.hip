@@ -284,6 +284,7 @@ RTR_DEV bool accept_tree(const Best &b, float t, uint32_t leaf) {
     return b.leaf == REF_NONE || t < b.t || (t == b.t && (leaf & REF_INDEX) > (b.leaf & REF_INDEX));
 }
 
+template <bool VOL>
 RTR_DEV void test_leaf(const RenderParams &p, uint32_t ref, const Ray &r, float a, Best &best, Rng &rng) {
     const float4 *hot = reinterpret_cast<const float4 *>(p.leaf_hot + (ref & REF_INDEX));
     float4 q0 = hot[0], q1 = hot[1], q2 = hot[2];
@@ -293,7 +294,7 @@ RTR_DEV void test_leaf(const RenderParams &p, uint32_t ref, const Ray &r, float 
             accept_tree(best, t, ref)) {
             best.t = t; best.u = u; best.v = v; best.leaf = ref;
         }
-    } else if (ref & REF_VOL) {
+    } else if (VOL && (ref & REF_VOL)) {
         float t;
         // Volume::hit(ray, tmin, +inf) as called from the tree (bvh.rs:156)
         if (volume_t(mk(q0.x, q0.y, q0.z), q1.x, q1.y, r, a, __builtin_inff(), rng, t) && accept_tree(best, t, ref)) {
@@ -314,6 +315,7 @@ RTR_DEV void test_leaf(const RenderParams &p, uint32_t ref, const Ray &r, float 
 // strictly beyond the best hit so far -- nothing inside it can win or tie.
 // tmax_box is the tmax the reference hands to AABB::hit: +inf from the scene tree, closest_so_far when a
 // mesh is reached from the linear world (scene.rs:147, mesh.rs:124-127).
+template <bool VOL>
 RTR_DEV void traverse(const RenderParams &p, uint32_t root, const Ray &r, V3 inv, float a, float tmax_box,
                       Best &best, uint32_t *stk_ref, float *stk_t, uint32_t lane, Rng &rng) {
     // Volume leaves draw a random number on every visit (volume.rs:57), so a subtree that holds one is visited
@@ -325,7 +327,7 @@ RTR_DEV void traverse(const RenderParams &p, uint32_t root, const Ray &r, V3 inv
         if (cur == REF_NONE) {
             pop = true;
         } else if (cur & REF_LEAF) {
-            test_leaf(p, cur, r, a, best, rng);
+            test_leaf<VOL>(p, cur, r, a, best, rng);
             pop = true;
         } else {
             const float4 *nq = reinterpret_cast<const float4 *>(p.nodes + cur);
@@ -334,7 +336,7 @@ RTR_DEV void traverse(const RenderParams &p, uint32_t root, const Ray &r, V3 inv
             float rmin[3] = {q1.z, q1.w, q2.x}, rmax[3] = {q2.y, q2.z, q2.w};
             uint32_t l = __float_as_uint(q3.x), rr = __float_as_uint(q3.y);
             const uint32_t flags = __float_as_uint(q3.z);
-            const bool lvol = flags & NODE_LVOL, rvol = flags & NODE_RVOL;
+            const bool lvol = VOL && (flags & NODE_LVOL), rvol = VOL && (flags & NODE_RVOL);
             bool hl = l != REF_NONE, hr = rr != REF_NONE;
             float el = 0.0f, er = 0.0f;
             if (hl && !(l & REF_LEAF)) {
@@ -396,6 +398,7 @@ RTR_DEV void face_forward(Hit &h, const Ray &r, V3 outward) {
 }
 
 // Build the HitRecord of the winning leaf (objects.rs:45-48 | mesh.rs:185-193).
+template <bool VOL>
 RTR_DEV void finish_leaf(const RenderParams &p, const Best &best, const Ray &r, Hit &h) {
     uint32_t L = best.leaf & REF_INDEX;
     const float4 *cold = reinterpret_cast<const float4 *>(p.leaf_cold + L);
@@ -414,7 +417,7 @@ RTR_DEV void finish_leaf(const RenderParams &p, const Best &best, const Ray &r, 
         bool use_face = (mag > 0.0f) || (mag == 0.0f && (dd < 0.0f || (dd == 0.0f && __builtin_signbit(dd))));
         if (use_face) n = fn;
         face_forward(h, r, n);
-    } else if (best.leaf & REF_VOL) {
+    } else if (VOL && (best.leaf & REF_VOL)) {
         face_forward(h, r, mk(1.0f, 0.0f, 0.0f)); // volume.rs:67: the arbitrary constant normal
     } else {
         const float4 *hot = reinterpret_cast<const float4 *>(p.leaf_hot + L);
@@ -432,7 +435,7 @@ struct SphereRegs {
 };
 
 // world.hit (render.rs:38).  Returns false on miss.
-template <uint32_t WORLD, uint32_t NS>
+template <uint32_t WORLD, uint32_t NS, bool VOL>
 RTR_DEV bool world_hit(const RenderParams &p, const Ray &r, Hit &h, uint32_t *stk_ref, float *stk_t, uint32_t lane,
                        const SphereRegs<NS> &sr, const uint32_t *lds_spheres, Rng &rng) {
     const float a = dot(r.d, r.d); // objects.rs:25, hoisted per ray
@@ -487,7 +490,7 @@ RTR_DEV bool world_hit(const RenderParams &p, const Ray &r, Hit &h, uint32_t *st
                 float e;
                 go = slab(p.root_box, p.root_box + 3, r, inv, __builtin_inff(), e);
             }
-            if (go) traverse(p, root, r, inv, a, __builtin_inff(), best, stk_ref, stk_t, lane, rng);
+            if (go) traverse<VOL>(p, root, r, inv, a, __builtin_inff(), best, stk_ref, stk_t, lane, rng);
         } else {
             // scene.rs:141-157 with meshes: object.hit(ray, tmin, closest_so_far); a mesh returns the nearest
             // triangle of the boxes that pass AABB::hit(.., closest_so_far) and Triangle::hit ignores tmax
@@ -501,7 +504,7 @@ RTR_DEV bool world_hit(const RenderParams &p, const Ray &r, Hit &h, uint32_t *st
                     const float4 *hot = reinterpret_cast<const float4 *>(p.leaf_hot + (ref & REF_INDEX));
                     float4 q0 = hot[0], q1 = hot[1];
                     float t;
-                    const bool got = (ref & REF_VOL) ? volume_t(mk(q0.x, q0.y, q0.z), q1.x, q1.y, r, a, closest, rng, t)
+                    const bool got = (VOL && (ref & REF_VOL)) ? volume_t(mk(q0.x, q0.y, q0.z), q1.x, q1.y, r, a, closest, rng, t)
                                                      : sphere_t(mk(q0.x, q0.y, q0.z), q1.x, r, a, closest, t);
                     if (got) {
                         closest = t; best.t = t; best.leaf = ref;
@@ -514,7 +517,7 @@ RTR_DEV bool world_hit(const RenderParams &p, const Ray &r, Hit &h, uint32_t *st
                         float e;
                         go = slab(o.box, o.box + 3, r, inv, closest, e);
                     }
-                    if (go) traverse(p, ref, r, inv, a, closest, local, stk_ref, stk_t, lane, rng);
+                    if (go) traverse<VOL>(p, ref, r, inv, a, closest, local, stk_ref, stk_t, lane, rng);
                     if (local.leaf != REF_NONE) {
                         closest = local.t;
                         best = local;
@@ -523,7 +526,7 @@ RTR_DEV bool world_hit(const RenderParams &p, const Ray &r, Hit &h, uint32_t *st
             }
         }
         if (best.leaf == REF_NONE) return false;
-        finish_leaf(p, best, r, h);
+        finish_leaf<VOL>(p, best, r, h);
         return true;
     }
 }
@@ -591,7 +594,7 @@ RTR_DEV V3 background(const RenderParams &p, const Ray &r) {
 #ifndef RTR_X_WAVES_PER_EU
 #define RTR_X_WAVES_PER_EU 1
 #endif
-template <uint32_t WORLD, uint32_t NS>
+template <uint32_t WORLD, uint32_t NS, bool VOL>
 __global__ __launch_bounds__(64, RTR_X_WAVES_PER_EU) void k_render(const RenderParams p) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const uint32_t lane = threadIdx.x;
@@ -680,7 +683,7 @@ __global__ __launch_bounds__(64, RTR_X_WAVES_PER_EU) void k_render(const RenderP
 #endif
         bool done;
         V3 term;
-        const bool was_hit = world_hit<WORLD, NS>(p, ray, h, stk_ref, stk_t, lane, sr, lds_spheres, rng);
+        const bool was_hit = world_hit<WORLD, NS, VOL>(p, ray, h, stk_ref, stk_t, lane, sr, lds_spheres, rng);
         RTR_STAMP(0)
         if (!was_hit) {
             term = background(p, ray);
@@ -856,7 +859,7 @@ hipError_t launch_selftest_sqrt(unsigned long long *d_mismatches, hipStream_t st
 // --- launchers (called from rtr_api.cpp) -----------------------------------------------------------------
 template <uint32_t NS>
 static void launch_spheres(const RenderParams &p, uint32_t grid, uint32_t lds_bytes, hipStream_t stream) {
-    hipLaunchKernelGGL((k_render<WORLD_LINEAR_SPHERES, NS>), dim3(grid), dim3(64), lds_bytes, stream, p);
+    hipLaunchKernelGGL((k_render<WORLD_LINEAR_SPHERES, NS, false>), dim3(grid), dim3(64), lds_bytes, stream, p);
 }
 
 hipError_t launch_render(const RenderParams &p, uint32_t grid, uint32_t lds_bytes, hipStream_t stream) {
@@ -874,8 +877,14 @@ hipError_t launch_render(const RenderParams &p, uint32_t grid, uint32_t lds_byte
         default: launch_spheres<0>(p, grid, lds_bytes, stream); break;
         }
         break;
-    case WORLD_BVH: hipLaunchKernelGGL((k_render<WORLD_BVH, 0>), dim3(grid), dim3(64), lds_bytes, stream, p); break;
-    default: hipLaunchKernelGGL((k_render<WORLD_LINEAR_GENERIC, 0>), dim3(grid), dim3(64), lds_bytes, stream, p); break;
+    case WORLD_BVH: // Volume leaves need the reference's visit set and order: a separate instantiation pays for it
+        if (p.has_volumes) hipLaunchKernelGGL((k_render<WORLD_BVH, 0, true>), dim3(grid), dim3(64), lds_bytes, stream, p);
+        else hipLaunchKernelGGL((k_render<WORLD_BVH, 0, false>), dim3(grid), dim3(64), lds_bytes, stream, p);
+        break;
+    default:
+        if (p.has_volumes) hipLaunchKernelGGL((k_render<WORLD_LINEAR_GENERIC, 0, true>), dim3(grid), dim3(64), lds_bytes, stream, p);
+        else hipLaunchKernelGGL((k_render<WORLD_LINEAR_GENERIC, 0, false>), dim3(grid), dim3(64), lds_bytes, stream, p);
+        break;
     }
     return hipGetLastError();
 }
@@ -890,19 +899,22 @@ hipError_t launch_resolve(const float *sum_rgba, uint32_t spp, uint32_t n_pixels
 hipError_t render_kernel_attributes(const RenderParams &p, int *vgprs, int *static_lds) {
     hipFuncAttributes attr;
     const void *fn;
-    if (p.world == WORLD_BVH) fn = reinterpret_cast<const void *>(k_render<WORLD_BVH, 0>);
-    else if (p.world == WORLD_LINEAR_GENERIC) fn = reinterpret_cast<const void *>(k_render<WORLD_LINEAR_GENERIC, 0>);
+    if (p.world == WORLD_BVH)
+        fn = p.has_volumes ? reinterpret_cast<const void *>(k_render<WORLD_BVH, 0, true>) : reinterpret_cast<const void *>(k_render<WORLD_BVH, 0, false>);
+    else if (p.world == WORLD_LINEAR_GENERIC)
+        fn = p.has_volumes ? reinterpret_cast<const void *>(k_render<WORLD_LINEAR_GENERIC, 0, true>)
+                           : reinterpret_cast<const void *>(k_render<WORLD_LINEAR_GENERIC, 0, false>);
     else {
         switch (p.sphere_regs) {
-        case 1: fn = reinterpret_cast<const void *>(k_render<WORLD_LINEAR_SPHERES, 1>); break;
-        case 2: fn = reinterpret_cast<const void *>(k_render<WORLD_LINEAR_SPHERES, 2>); break;
-        case 3: fn = reinterpret_cast<const void *>(k_render<WORLD_LINEAR_SPHERES, 3>); break;
-        case 4: fn = reinterpret_cast<const void *>(k_render<WORLD_LINEAR_SPHERES, 4>); break;
-        case 5: fn = reinterpret_cast<const void *>(k_render<WORLD_LINEAR_SPHERES, 5>); break;
-        case 6: fn = reinterpret_cast<const void *>(k_render<WORLD_LINEAR_SPHERES, 6>); break;
-        case 7: fn = reinterpret_cast<const void *>(k_render<WORLD_LINEAR_SPHERES, 7>); break;
-        case 8: fn = reinterpret_cast<const void *>(k_render<WORLD_LINEAR_SPHERES, 8>); break;
-        default: fn = reinterpret_cast<const void *>(k_render<WORLD_LINEAR_SPHERES, 0>); break;
+        case 1: fn = reinterpret_cast<const void *>(k_render<WORLD_LINEAR_SPHERES, 1, false>); break;
+        case 2: fn = reinterpret_cast<const void *>(k_render<WORLD_LINEAR_SPHERES, 2, false>); break;
+        case 3: fn = reinterpret_cast<const void *>(k_render<WORLD_LINEAR_SPHERES, 3, false>); break;
+        case 4: fn = reinterpret_cast<const void *>(k_render<WORLD_LINEAR_SPHERES, 4, false>); break;
+        case 5: fn = reinterpret_cast<const void *>(k_render<WORLD_LINEAR_SPHERES, 5, false>); break;
+        case 6: fn = reinterpret_cast<const void *>(k_render<WORLD_LINEAR_SPHERES, 6, false>); break;
+        case 7: fn = reinterpret_cast<const void *>(k_render<WORLD_LINEAR_SPHERES, 7, false>); break;
+        case 8: fn = reinterpret_cast<const void *>(k_render<WORLD_LINEAR_SPHERES, 8, false>); break;
+        default: fn = reinterpret_cast<const void *>(k_render<WORLD_LINEAR_SPHERES, 0, false>); break;
         }
     }
     hipError_t e = hipFuncGetAttributes(&attr, fn);
