@@ -100,7 +100,7 @@ class Builder {
             if (c != c) nan_seen = true;
         }
         if (!nan_seen)
-            std::stable_sort(h.begin() + (ptrdiff_t)b, h.begin() + (ptrdiff_t)e, [&](uint32_t p, uint32_t q) {
+            std::stable_sort(h.begin() + (std::ptrdiff_t)b, h.begin() + (std::ptrdiff_t)e, [&](uint32_t p, uint32_t q) {
                 return centroid(bounds_[p], axis) < centroid(bounds_[q], axis);
             });
         size_t mid = b + n / 2;
