@@ -161,26 +161,26 @@ RTR_DEV uint32_t sat_u8(float f) {
 struct Ray { V3 o, d; };
 
 // aabb.rs:81-137 with 1/d hoisted per ray.  Returns hit; *entry = the narrowed tmin.
+// The reference narrows [tmin, tmax] per axis with `if t0 > tmin { tmin = t0 }`, `if t1 < tmax { tmax = t1 }` and
+// returns false as soon as `tmax <= tmin`.  Restated without changing any outcome:
+//   * the running tmin / tmax are never NaN (tmin starts at 1e-5, tmax at +inf or a hit distance; a NaN t0 / t1
+//     -- 0 * inf when the direction component is 0 and the origin lies on the slab plane -- fails its comparison
+//     and is ignored), so the conditional updates are exactly fmaxf / fminf (IEEE maxNum / minNum drop the NaN);
+//   * tmin only grows and tmax only shrinks, so "tmax <= tmin after some axis" is equivalent to
+//     "tmax <= tmin after the last axis": one comparison instead of three.
 RTR_DEV bool slab(const float *bmin, const float *bmax, const Ray &r, V3 inv, float tmax, float &entry) {
     float tmin = kTMin;
-    bool fail;
     float t0 = (bmin[0] - r.o.x) * inv.x, t1 = (bmax[0] - r.o.x) * inv.x;
-    if (inv.x < 0.0f) { float t = t0; t0 = t1; t1 = t; }
-    if (t0 > tmin) tmin = t0;
-    if (t1 < tmax) tmax = t1;
-    fail = tmax <= tmin;
+    tmin = fmaxf(tmin, inv.x < 0.0f ? t1 : t0); // `if inv_d < 0 { swap(t0, t1) }`
+    tmax = fminf(tmax, inv.x < 0.0f ? t0 : t1);
     t0 = (bmin[1] - r.o.y) * inv.y; t1 = (bmax[1] - r.o.y) * inv.y;
-    if (inv.y < 0.0f) { float t = t0; t0 = t1; t1 = t; }
-    if (t0 > tmin) tmin = t0;
-    if (t1 < tmax) tmax = t1;
-    fail = fail || (tmax <= tmin);
+    tmin = fmaxf(tmin, inv.y < 0.0f ? t1 : t0);
+    tmax = fminf(tmax, inv.y < 0.0f ? t0 : t1);
     t0 = (bmin[2] - r.o.z) * inv.z; t1 = (bmax[2] - r.o.z) * inv.z;
-    if (inv.z < 0.0f) { float t = t0; t0 = t1; t1 = t; }
-    if (t0 > tmin) tmin = t0;
-    if (t1 < tmax) tmax = t1;
-    fail = fail || (tmax <= tmin);
+    tmin = fmaxf(tmin, inv.z < 0.0f ? t1 : t0);
+    tmax = fminf(tmax, inv.z < 0.0f ? t0 : t1);
     entry = tmin;
-    return !fail;
+    return !(tmax <= tmin);
 }
 
 // objects.rs:22-51 root selection.  a = |d|^2.  Returns true with t when a root lies in [tmin, tmax].
@@ -273,6 +273,17 @@ RTR_DEV bool triangle_t(V3 v0, V3 e1, V3 e2, const Ray &r, float &t, float &u, f
     return true;
 }
 
+// hipcc sinks the individual 16-B loads of a node / leaf record into the branches that consume them, which turns
+// one gather into two or three DEPENDENT round trips on a latency-bound loop.  Naming every component as an input
+// of one empty asm statement pins all loads of the record in front of it: they issue together, one wait covers them.
+RTR_DEV void gather_fence(const float4 &a, const float4 &b, const float4 &c) {
+    asm volatile("" ::"v"(a.x), "v"(a.y), "v"(a.z), "v"(a.w), "v"(b.x), "v"(b.y), "v"(b.z), "v"(b.w), "v"(c.x), "v"(c.y), "v"(c.z), "v"(c.w));
+}
+RTR_DEV void gather_fence(const float4 &a, const float4 &b, const float4 &c, const float4 &d) {
+    asm volatile("" ::"v"(a.x), "v"(a.y), "v"(a.z), "v"(a.w), "v"(b.x), "v"(b.y), "v"(b.z), "v"(b.w), "v"(c.x), "v"(c.y), "v"(c.z), "v"(c.w),
+                 "v"(d.x), "v"(d.y), "v"(d.z), "v"(d.w));
+}
+
 struct Best {
     float t, u, v;
     uint32_t leaf; // REF_LEAF|type|L, or REF_NONE
@@ -288,6 +299,9 @@ template <bool VOL>
 RTR_DEV void test_leaf(const RenderParams &p, uint32_t ref, const Ray &r, float a, Best &best, Rng &rng) {
     const float4 *hot = reinterpret_cast<const float4 *>(p.leaf_hot + (ref & REF_INDEX));
     float4 q0 = hot[0], q1 = hot[1], q2 = hot[2];
+#ifndef RTR_X_NO_GATHER_FENCE
+    gather_fence(q0, q1, q2);
+#endif
     if (ref & REF_TRI) {
         float t, u, v;
         if (triangle_t(mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y), mk(q1.z, q1.w, q2.x), r, t, u, v) &&
@@ -332,6 +346,9 @@ RTR_DEV void traverse(const RenderParams &p, uint32_t root, const Ray &r, V3 inv
         } else {
             const float4 *nq = reinterpret_cast<const float4 *>(p.nodes + cur);
             float4 q0 = nq[0], q1 = nq[1], q2 = nq[2], q3 = nq[3];
+#ifndef RTR_X_NO_GATHER_FENCE
+            gather_fence(q0, q1, q2, q3);
+#endif
             float lmin[3] = {q0.x, q0.y, q0.z}, lmax[3] = {q0.w, q1.x, q1.y};
             float rmin[3] = {q1.z, q1.w, q2.x}, rmax[3] = {q2.y, q2.z, q2.w};
             uint32_t l = __float_as_uint(q3.x), rr = __float_as_uint(q3.y);
@@ -341,11 +358,11 @@ RTR_DEV void traverse(const RenderParams &p, uint32_t root, const Ray &r, V3 inv
             float el = 0.0f, er = 0.0f;
             if (hl && !(l & REF_LEAF)) {
                 hl = slab(lmin, lmax, r, inv, tmax_box, el);
-                if (!lvol && best.leaf != REF_NONE && el > best.t) hl = false;
+                if (!lvol && el > best.t) hl = false; // best.t is +inf until a leaf is hit
             }
             if (hr && !(rr & REF_LEAF)) {
                 hr = slab(rmin, rmax, r, inv, tmax_box, er);
-                if (!rvol && best.leaf != REF_NONE && er > best.t) hr = false;
+                if (!rvol && er > best.t) hr = false;
             }
             if (hl && hr) {
                 bool sw = er < el;
@@ -375,7 +392,7 @@ RTR_DEV void traverse(const RenderParams &p, uint32_t root, const Ray &r, V3 inv
                 sp--;
                 uint32_t c = stk_ref[sp * 64 + lane];
                 float e = stk_t[sp * 64 + lane];
-                if (best.leaf != REF_NONE && e > best.t) continue;
+                if (e > best.t) continue; // its box is entered beyond the best hit (never for -inf entries)
                 cur = c;
                 got = true;
                 break;
