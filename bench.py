@@ -6,10 +6,12 @@
     workload scenes/benchmark.json at 1920x1080, 256 spp, depth 6, clamp 10 (BASELINE configs[1])
     step     one whole frame: integrate + clamp + mean + sqrt gamma + RGBA8, output resident in HBM
 
-N = 1: one fused kernel per frame.  N > 1 (one process per GPU, launched by torch.distributed.run): the
-frame's 8x8-pixel tiles are dealt round-robin to the ranks, each rank integrates its tiles into a zeroed
-float4 sum buffer, the buffers are summed onto rank 0 with one RCCL reduce over xGMI, rank 0 resolves to
-RGBA8.  The total work is the fixed frame, so scaling is "strong".
+N = 1: one fused kernel per frame.  N > 1 (one process per GPU, launched by torch.distributed.run): the samples
+of every pixel are split over the ranks (each rank integrates all pixels for its share of the samples, so every GPU
+keeps a full grid of short waves), the per-pixel partial sums are summed onto rank 0 with one RCCL reduce over
+xGMI, rank 0 resolves to RGBA8; frame i's reduce overlaps frame i+1's integrate.  `--split tiles` selects the
+8x8-tile decomposition instead (bit-identical to one GPU, but under-fills the GPUs).  The total work is the fixed
+frame, so scaling is "strong".
 
 Prints ONE JSON line on rank 0.
 """
@@ -83,6 +85,9 @@ def parse_args():
     ap.add_argument("--cpu-spp", type=int, default=0,
                     help="spp of the bounded CPU-baseline sample (0 = size it for ~15 s of CPU work)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--split", choices=["samples", "tiles"], default="samples",
+                    help="multi-GPU decomposition: split the samples of every pixel over the ranks (default: full "
+                         "grids of short waves, perfect balance) or 8x8 tiles round-robin (bit-identical to one GPU)")
     ap.add_argument("--pmc-traffic", type=float, default=None,
                     help="HBM bytes per launch from a separate rocprofv3 --pmc pass (profiles/), if collected")
     return ap.parse_args()
@@ -153,7 +158,7 @@ def main():
     r.upload_scene(scene)
     rgba8 = torch.zeros((H, W, 4), dtype=torch.uint8, device=dev)
     # N > 1: double-buffered integrate | RCCL reduce + resolve pipeline (raytracingrust_amd/distributed.py)
-    pipe = FramePipeline(r, W, H, args.spp, dev) if distributed else None
+    pipe = FramePipeline(r, W, H, args.spp, dev, split=args.split) if distributed else None
     # one explicit HIP stream for kernels, torch ops and RCCL alike (a NULL stream would mean "the context's own")
     tstream = torch.cuda.Stream(device=dev)
     torch.cuda.synchronize()
@@ -223,7 +228,9 @@ def main():
                 "workload": f"{os.path.basename(args.scene)} {W}x{H} {args.spp}spp depth {scene.settings.max_ray_depth} "
                             f"clamp {scene.settings.clamp_indirect:g} "
                             f"{'BVH' if scene.settings.enable_bvh_tree else 'linear'} world",
-                "sharding": "single fused kernel" if world == 1 else f"8x8 tiles round-robin over {world} ranks + RCCL reduce",
+                "sharding": "single fused kernel" if pipe is None else (
+                    f"samples of every pixel split over {world} ranks + RCCL reduce (sum of partial sums)"
+                    if pipe.split == "samples" else f"8x8 tiles round-robin over {world} ranks + RCCL reduce"),
                 "ms_per_frame": round(ms_per_step, 4),
                 "msamples_per_s": round(W * H * args.spp * args.steps / elapsed / 1e6, 2),
                 "segments_per_frame": int(total_segments / max(args.steps, 1)),

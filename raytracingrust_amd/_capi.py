@@ -97,6 +97,8 @@ SYMBOLS = [
                                           C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p]),
     ("rtr_render_tiles_device", C.c_int, [_ctx, C.POINTER(rtr_camera), C.POINTER(rtr_settings), C.c_uint32,
                                           C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),
+    ("rtr_render_samples_device", C.c_int, [_ctx, C.POINTER(rtr_camera), C.POINTER(rtr_settings), C.c_uint32,
+                                            C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),
     ("rtr_resolve_device", C.c_int, [_ctx, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p,
                                      C.c_void_p]),
     ("rtr_get_stats", C.c_int, [_ctx, C.POINTER(rtr_stats)]),

@@ -108,7 +108,7 @@ int check_settings(rtr_context *ctx, const rtr_camera *camera, const rtr_setting
 // Fill the launch parameters and launch the integrator.  Exactly one of (sum_rgba) / (rgba8|mean_rgb) is used.
 int launch_frame(rtr_context *ctx, const rtr_camera *camera, const rtr_settings *st, uint32_t width, uint32_t height,
                  uint64_t seed, uint32_t shard, uint32_t n_shards, float *d_sum_rgba, uint8_t *d_rgba8, float *d_mean_rgb,
-                 hipStream_t stream) {
+                 hipStream_t stream, uint32_t sample_begin = 0u, uint32_t sample_count = 0xFFFFFFFFu) {
     if (!ctx) return RTR_ERR_INVALID_ARGUMENT;
     if (ctx->device < 0) return fail(ctx, RTR_ERR_NO_DEVICE, "host-only context: no HIP device bound (there is no CPU fallback)");
     if (!ctx->have_scene) return fail(ctx, RTR_ERR_NO_SCENE, "rtr_upload_scene has not been called");
@@ -126,6 +126,10 @@ int launch_frame(rtr_context *ctx, const rtr_camera *camera, const rtr_settings 
     p.height_m1 = (float)(height - 1u); // render.rs:89
     p.width = width; p.height = height;
     p.spp = st->samples_per_pixel; p.max_depth = st->max_ray_depth; p.mode = st->mode;
+    if (sample_count == 0xFFFFFFFFu) { sample_begin = 0u; sample_count = p.spp; }
+    if (sample_begin > p.spp || sample_count > p.spp - sample_begin)
+        return fail(ctx, RTR_ERR_INVALID_ARGUMENT, "sample range exceeds samples_per_pixel");
+    p.sample_begin = sample_begin; p.sample_count = sample_count;
     p.clamp_indirect = st->clamp_indirect;
     p.seed_lo = (uint32_t)seed; p.seed_hi = (uint32_t)(seed >> 32);
     // render.rs:68-72: the tree when enable_bvh_tree, else the linear scan of scene.rs:141-157
@@ -178,7 +182,7 @@ int launch_frame(rtr_context *ctx, const rtr_camera *camera, const rtr_settings 
             uint32_t h = (ty * 8u + 8u <= height) ? 8u : height - ty * 8u;
             pixels += (uint64_t)w * h;
         }
-        ctx->last_primary = pixels * st->samples_per_pixel;
+        ctx->last_primary = pixels * sample_count;
     }
     RTR_HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters + slot, 0, sizeof(unsigned long long), stream));
     RTR_HIP_TRY(ctx, hipEventRecord(ctx->ev_start[slot], stream));
@@ -333,6 +337,15 @@ int rtr_render_tiles_device(rtr_context *ctx, const rtr_camera *camera, const rt
     if (!ctx) return RTR_ERR_INVALID_ARGUMENT;
     if (!d_sum_rgba) return fail(ctx, RTR_ERR_INVALID_ARGUMENT, "null output");
     return launch_frame(ctx, camera, settings, width, height, seed, shard, n_shards, d_sum_rgba, nullptr, nullptr, (hipStream_t)stream);
+}
+
+int rtr_render_samples_device(rtr_context *ctx, const rtr_camera *camera, const rtr_settings *settings, uint32_t width,
+                              uint32_t height, uint64_t seed, uint32_t sample_begin, uint32_t sample_count,
+                              float *d_sum_rgba, void *stream) {
+    if (!ctx) return RTR_ERR_INVALID_ARGUMENT;
+    if (!d_sum_rgba) return fail(ctx, RTR_ERR_INVALID_ARGUMENT, "null output");
+    return launch_frame(ctx, camera, settings, width, height, seed, 0u, 1u, d_sum_rgba, nullptr, nullptr, (hipStream_t)stream,
+                        sample_begin, sample_count);
 }
 
 int rtr_resolve_device(rtr_context *ctx, const float *d_sum_rgba, uint32_t samples_per_pixel, uint32_t width,

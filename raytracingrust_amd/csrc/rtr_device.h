@@ -82,7 +82,8 @@ struct RenderParams {
     float cam_origin[3], cam_horizontal[3], cam_vertical[3], cam_llc[3];
     float width_m1, height_m1; // (W-1) as f32, (H-1) as f32  (render.rs:88-89)
     uint32_t width, height;
-    uint32_t spp, max_depth, mode;
+    uint32_t spp, max_depth, mode;   // spp: the frame's samples per pixel (the divisor of the fused resolve)
+    uint32_t sample_begin, sample_count; // the samples this launch integrates (whole frame: 0, spp)
     float clamp_indirect;
     uint32_t seed_lo, seed_hi;
     // world

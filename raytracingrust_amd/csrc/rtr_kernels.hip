@@ -662,8 +662,10 @@ __global__ __launch_bounds__(64, RTR_X_WAVES_PER_EU) void k_render(const RenderP
 
     V3 acc = mk(0.0f, 0.0f, 0.0f);
     uint32_t nseg = 0;
-    const uint32_t spp = (inside && p.max_depth > 0u) ? p.spp : 0u;
-    uint32_t s = 0, depth = 0, nchain = 0;
+    // samples [sample_begin, sample_begin + sample_count) of this pixel; the random stream is keyed by the
+    // absolute sample index, so a frame split by samples over several launches / GPUs draws the same numbers
+    const uint32_t spp = (inside && p.max_depth > 0u) ? p.sample_begin + p.sample_count : 0u;
+    uint32_t s = p.sample_begin, depth = 0, nchain = 0;
     Ray ray;
     ray.o = cam_o; ray.d = cam_o;
 
@@ -677,7 +679,7 @@ __global__ __launch_bounds__(64, RTR_X_WAVES_PER_EU) void k_render(const RenderP
         ray.d = sub(sub(add(cam_llc, scale(cam_h, u)), scale(cam_v, v)), cam_o);
         depth = 0; nchain = 0;
     };
-    if (spp > 0u) start_sample(0u);
+    if (s < spp) start_sample(s);
 
 #ifdef RTR_X_COUNT_ITERS // diagnostic build only: the segment counter returns wave-iterations*64 instead
     uint32_t n_iter = 0;

@@ -132,6 +132,13 @@ class Renderer:
                                                       C.c_uint64(seed), shard, n_shards, C.c_void_p(d_sum_ptr),
                                                       C.c_void_p(stream)))
 
+    def render_samples_device(self, width: int, height: int, seed: int, sample_begin: int, sample_count: int,
+                              d_sum_ptr: int, stream: int = 0, scene: Optional[Scene] = None) -> None:
+        cam, st = self._cam_settings(scene)
+        self._check(self._lib.rtr_render_samples_device(self._ctx, C.byref(cam), C.byref(st), width, height,
+                                                        C.c_uint64(seed), sample_begin, sample_count,
+                                                        C.c_void_p(d_sum_ptr), C.c_void_p(stream)))
+
     def resolve_device(self, d_sum_ptr: int, spp: int, width: int, height: int, d_rgba8_ptr: int = 0,
                        d_mean_ptr: int = 0, stream: int = 0) -> None:
         self._check(self._lib.rtr_resolve_device(self._ctx, C.c_void_p(d_sum_ptr), spp, width, height,

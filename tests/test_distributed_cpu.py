@@ -79,3 +79,16 @@ def test_gloo_sharded_frame_equals_single_frame(tmp_path, world):
     assert np.array_equal(out["accum"][..., :3].view(np.uint32), mean.view(np.uint32))  # bit-identical: x + 0 = x
     assert np.all(out["accum"][..., 3] == 0)
     assert np.all(out["rgba8"][..., 3] == 255)
+
+
+def test_sample_ranges_partition_the_samples():
+    for spp in [1, 5, 13, 256, 1024]:
+        for n in [1, 2, 3, 4, 8]:
+            ranges = [rd.sample_range(r, n, spp) for r in range(n)]
+            assert ranges[0][0] == 0 and sum(c for _, c in ranges) == spp
+            for (b0, c0), (b1, _) in zip(ranges, ranges[1:]):
+                assert b1 == b0 + c0
+            counts = [c for _, c in ranges]
+            assert max(counts) - min(counts) <= 1
+    with pytest.raises(ValueError):
+        rd.sample_range(3, 3, 8)

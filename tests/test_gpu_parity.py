@@ -275,3 +275,43 @@ def test_empty_scene_and_extreme_settings(gpu_renderer):
     bad = benchmark_scene(1, max_ray_depth=256)
     with pytest.raises(rt.RtrError):
         r.render(8, 8, scene=bad)
+
+
+@pytest.mark.parametrize("n_shards", [2, 3, 8])
+def test_sample_sharded_frame_matches_within_float_sum_order(gpu_renderer, n_shards):
+    """The multi-GPU decomposition bench.py uses (rtr_render_samples_device): every shard integrates all pixels for
+    its contiguous share of the samples.  Draws are identical to the single launch (streams are keyed by the absolute
+    sample index: the segment counts add up exactly); only the float addition order of the per-pixel sums differs,
+    so the frame matches to ~1e-7 relative and the RGBA8 image to +-1."""
+    import torch
+
+    from raytracingrust_amd.distributed import sample_range
+
+    w, h, seed = 96, 56, 77
+    scene = simple_scene(13)  # 13 spp: uneven shares
+    r = gpu_renderer
+    r.upload_scene(scene)
+    rgba_f, mean_f = r.render(w, h, seed=seed, want_rgba8=True, want_mean=True)
+    seg_f = r.stats().segments
+    dev = torch.device("cuda", 0)
+    total = torch.zeros((h, w, 4), dtype=torch.float32, device=dev)
+    segs, covered = 0, 0
+    for shard in range(n_shards):
+        begin, count = sample_range(shard, n_shards, 13)
+        assert begin == covered
+        covered += count
+        part = torch.full((h, w, 4), 5.0, dtype=torch.float32, device=dev)  # every pixel must be overwritten
+        torch.cuda.synchronize()
+        r.render_samples_device(w, h, seed, begin, count, part.data_ptr(), 0)
+        segs += r.stats().segments
+        total += part
+    assert covered == 13 and segs == seg_f
+    rgba = torch.zeros((h, w, 4), dtype=torch.uint8, device=dev)
+    mean = torch.zeros((h, w, 3), dtype=torch.float32, device=dev)
+    torch.cuda.synchronize()
+    r.resolve_device(total.data_ptr(), 13, w, h, rgba.data_ptr(), mean.data_ptr(), 0)
+    r.stats()
+    c = compare(mean.cpu().numpy(), rgba.cpu().numpy(), mean_f, rgba_f)
+    assert max(c["rel_l2"]) <= 1e-6 and c["max_u8_delta"] <= 1, c
+    with pytest.raises(rt.RtrError):
+        r.render_samples_device(w, h, seed, 10, 4, total.data_ptr(), 0)  # 10 + 4 > 13
