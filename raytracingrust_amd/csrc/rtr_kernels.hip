@@ -462,6 +462,74 @@ RTR_DEV bool world_hit(const RenderParams &p, const Ray &r, Hit &h, uint32_t *st
         // +10 VGPRs and an LDS fetch per candidate outweigh the skipped root blocks.)
         float closest = __builtin_inff();
         int best = -1;
+#ifndef RTR_X_NO_DEFERRED_DIVISION
+        // Deferred division.  Sphere::hit divides each root's numerator n = -half_b -/+ sqrt(disc) by a = |d|^2 only
+        // to COMPARE the quotient with tmin and with closest_so_far (objects.rs:38-44); all roots of one ray share
+        // the denominator, so the comparisons can be made on the numerators:
+        //     q = RN(n / a) < tmin        is certain when  n < tmin*a*(1 - 2^-20),   its negation when  n > tmin*a*(1 + 2^-20)
+        //     RN(nb / a) < RN(n / a)      is certain when  n > nb*(1 + 2^-20),       its negation when  n < nb*(1 - 2^-20)
+        // (a > 0; one rounding moves a quotient by 2^-24 relative, the products carry 2^-23, the margin is 2^-20).
+        // closest_so_far is kept as the numerator nb of the accepted root and divided once, for the winner: the
+        // very value the reference stored.  A lane for which ANY needed comparison falls inside a margin (or whose a
+        // is not a normal number in [2^-60, 2^60], or that meets a NaN) repeats the whole scan with the reference's
+        // divisions below, so every decision is the reference's; the band is ~1e-6 wide, the repeat is rare.
+        {
+            const bool safe = a >= 0x1p-60f && a <= 0x1p60f;
+            const float ta = kTMin * a;
+            const float ta_lo = ta * 0x1.ffffep-1f, ta_hi = ta * 0x1.00001p+0f;
+            float nb = __builtin_inff(), nb_lo = __builtin_inff(), nb_hi = __builtin_inff();
+            bool amb = !safe;
+#pragma unroll
+            for (uint32_t i = 0; i < NS; i++) {
+                V3 oc = sub(r.o, mk(sr.cx[i], sr.cy[i], sr.cz[i]));
+                float half_b = dot(oc, r.d);
+                float cc = dot(oc, oc) - sr.r2[i];
+                float disc = half_b * half_b - a * cc;
+                if (!(disc < 0.0f)) { // objects.rs:31-33 (a NaN discriminant goes on, as in the reference)
+                    const float sq = rt_sqrt(disc);
+                    const float n1 = -half_b - sq, n2 = -half_b + sq;
+                    float n_acc = n1;
+                    bool acc = false;
+                    if (n1 < ta_lo) {            // first root certainly < tmin: the second root decides
+                        if (n2 < ta_lo || n2 > nb_hi) {
+                            // certainly < tmin, or certainly beyond closest_so_far: None
+                        } else if (n2 > ta_hi && n2 < nb_lo) {
+                            acc = true; n_acc = n2;
+                        } else {
+                            amb = true;
+                        }
+                    } else if (n1 > nb_hi) {
+                        // first root certainly beyond closest_so_far, the second lies farther still: None
+                    } else if (n1 > ta_hi && n1 < nb_lo) {
+                        acc = true;
+                    } else {
+                        amb = true;
+                    }
+                    if (acc) {
+                        nb = n_acc; nb_lo = n_acc * 0x1.ffffep-1f; nb_hi = n_acc * 0x1.00001p+0f;
+                        best = (int)i;
+                    }
+                }
+            }
+#ifdef RTR_X_COUNT_AMB // diagnostic build only: the segment counter counts exact-path repeats instead
+            if (amb) atomicAdd(p.counter, 0x100000000ull);
+#endif
+            if (!amb) {
+                if (best >= 0) closest = nb / a;
+            } else {
+                closest = __builtin_inff();
+                best = -1;
+                for (uint32_t i = 0; i < NS; i++) { // the reference's scan, divisions and all
+                    const float4 w = *reinterpret_cast<const float4 *>(lds_spheres + i * 8);
+                    float t;
+                    if (sphere_t(mk(w.x, w.y, w.z), __uint_as_float(lds_spheres[i * 8 + 4]), r, a, closest, t)) {
+                        closest = t;
+                        best = (int)i;
+                    }
+                }
+            }
+        }
+#else
 #pragma unroll
         for (uint32_t i = 0; i < NS; i++) {
             float t;
@@ -470,6 +538,7 @@ RTR_DEV bool world_hit(const RenderParams &p, const Ray &r, Hit &h, uint32_t *st
                 best = (int)i;
             }
         }
+#endif
         if (best < 0) return false;
         const float4 w = *reinterpret_cast<const float4 *>(lds_spheres + best * 8); // centre, radius
         h.material = lds_spheres[best * 8 + 5];
