@@ -315,3 +315,17 @@ def test_sample_sharded_frame_matches_within_float_sum_order(gpu_renderer, n_sha
     assert max(c["rel_l2"]) <= 1e-6 and c["max_u8_delta"] <= 1, c
     with pytest.raises(rt.RtrError):
         r.render_samples_device(w, h, seed, 10, 4, total.data_ptr(), 0)  # 10 + 4 > 13
+
+
+@pytest.mark.parametrize("config,spp", [("c1", 2), ("c4", 1), ("c3l", 1)])
+def test_full_size_frames_against_the_oracle(gpu_renderer, config, spp):
+    """BASELINE's frame size (1920x1080) for the tree worlds -- C1 (simple.json), C4 (house + plane, mix material, HDRI)
+    and C3's geometry (monkey + plane, HDRI) -- at low spp, whole frame against the oracle (polynomial trig mode)."""
+    from raytracingrust_amd.configs import baseline_config
+
+    scene, w, h = baseline_config(config, spp)
+    c, st, o_st = run_both(gpu_renderer, scene, w, h, 4242)
+    assert st.segments == o_st.segments
+    assert max(c["rel_l2"]) <= TOL and c["max_u8_delta"] <= 1, c
+    has_mesh = any(isinstance(o, rt.Mesh) for o in scene.objects)
+    assert c["mismatched_pixels"] <= (20 if has_mesh else 0), c  # culled vs unculled walk: ulp-level ties only
