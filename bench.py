@@ -64,6 +64,7 @@ def valu_issue(args, world, kernel_ms):
     ach = float(d["sq_insts_valu_per_launch"]) / (kernel_ms * 1e-3)
     return {"wave_insts_per_launch": float(d["sq_insts_valu_per_launch"]), "achieved_per_s": round(ach, 0),
             "peak_per_s": peak, "frac": round(ach / peak, 4),
+            "active_lane_fraction": d.get("active_lane_fraction"),  # SQ_THREAD_CYCLES_VALU / (SQ_ACTIVE_INST_VALU * 64)
             "source": "SQ_INSTS_VALU from profiles/r01 (same command), kernel time from this run's HIP events; "
                       "half-rate (compare/select/int-mul) and quarter-rate (sqrt/rcp) instructions make 1.0 unreachable"}
 
