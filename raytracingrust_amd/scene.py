@@ -282,6 +282,16 @@ class SkyMap:
             raise ValueError("SkyMap image must be HxWx3 and non-empty")
         self.image = img
 
+    @classmethod
+    def new(cls, path: str) -> "SkyMap":
+        """SkyMap::new (backgrounds.rs:58-81): texels from an OpenEXR file (raytracingrust_amd/exr.py: scanline files,
+        none / RLE / ZIPS / ZIP compression) or from a float32 `.npy` array of shape [height, width, 3]."""
+        if path.lower().endswith(".npy"):
+            return cls(np.load(path, allow_pickle=False))
+        from .exr import read_exr
+
+        return cls(read_exr(path))
+
     @property
     def width(self) -> int:
         return self.image.shape[1]
