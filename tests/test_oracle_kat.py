@@ -329,3 +329,19 @@ def test_skymap_lookup_orientation():
     # (the centre pixel's jittered ray points slightly right of and below the view axis)
     assert fwd[0] in (H - 1 - H // 2, H - H // 2) and fwd[1] in ((3 * W) // 4 - 1, (3 * W) // 4)
     assert look([1, 0, 0])[1] in (W // 2 - 1, W // 2)  # phi = atan2(-0, 1) + pi = pi -> v = .5
+
+
+def test_polynomial_vs_libm_trig_on_a_skymap_frame():
+    """The HIP kernels (and the oracle's parity mode) evaluate SkyMap's acos/atan2 with polynomials; the reference calls
+    libm.  On a BASELINE-style HDRI frame the two differ only where a lookup sits on a texel border: far inside the
+    1e-4 relative-L2 tolerance, RGBA8 identical."""
+    from helpers import compare
+    from raytracingrust_amd.configs import baseline_config
+
+    scene, _, _ = baseline_config("c3l", 4)
+    a = pyoracle.OracleScene(scene, trig_mode=pyoracle.TRIG_POLY).render(240, 135, 5, threads=0)
+    b = pyoracle.OracleScene(scene, trig_mode=pyoracle.TRIG_LIBM).render(240, 135, 5, threads=0)
+    assert a[2].sky_lookups == b[2].sky_lookups > 10000
+    c = compare(a[1], a[0], b[1], b[0])
+    assert max(c["rel_l2"]) < 1e-5 and c["max_u8_delta"] <= 1, c
+    assert c["mismatched_pixels"] < 0.01 * 240 * 135
