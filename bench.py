@@ -89,6 +89,8 @@ def parse_args():
     ap.add_argument("--split", choices=["samples", "tiles"], default="samples",
                     help="multi-GPU decomposition: split the samples of every pixel over the ranks (default: full "
                          "grids of short waves, perfect balance) or 8x8 tiles round-robin (bit-identical to one GPU)")
+    ap.add_argument("--mesh-tree", choices=["reference", "sah"], default="reference",
+                    help="mesh subtrees: the reference's median split (parity) or the binned-SAH rebuild (faster walk)")
     ap.add_argument("--pmc-traffic", type=float, default=None,
                     help="HBM bytes per launch from a separate rocprofv3 --pmc pass (profiles/), if collected")
     return ap.parse_args()
@@ -156,6 +158,7 @@ def main():
         W, H = args.width, args.height
 
     r = rt.Renderer(local_rank)
+    r.set_option("mesh_tree", args.mesh_tree)
     r.upload_scene(scene)
     rgba8 = torch.zeros((H, W, 4), dtype=torch.uint8, device=dev)
     # N > 1: double-buffered integrate | RCCL reduce + resolve pipeline (raytracingrust_amd/distributed.py)

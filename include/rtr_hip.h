@@ -186,6 +186,14 @@ void rtr_destroy(rtr_context *ctx);
 const char *rtr_last_error(const rtr_context *ctx);
 int rtr_abi_version(void);
 
+/* Context options (strings; applied at the next rtr_upload_scene):
+ *   "mesh_tree" = "reference" (default): every mesh subtree is the reference's median-split tree (mesh.rs:119-121),
+ *                 the parity configuration;
+ *               = "sah": mesh subtrees rebuilt with a binned surface-area heuristic over the same triangle boxes
+ *                 (SURVEY section 8f N1).  Closest hits are the same and exact-t ties still resolve by the reference's
+ *                 depth-first leaf rank; only ulp-level box-boundary cases can differ.  About half the traversal work
+ *                 on assets/house.obj. */
+int rtr_set_option(rtr_context *ctx, const char *name, const char *value);
 /* Lower + build + flatten + copy to HBM.  Replaces any previous scene of the context. */
 int rtr_upload_scene(rtr_context *ctx, const rtr_scene_desc *scene);
 int rtr_scene_info_get(const rtr_context *ctx, rtr_scene_info *out);

@@ -84,6 +84,7 @@ SYMBOLS = [
     ("rtr_create", C.c_int, [C.c_int, C.POINTER(_ctx)]),
     ("rtr_destroy", None, [_ctx]),
     ("rtr_last_error", C.c_char_p, [_ctx]),
+    ("rtr_set_option", C.c_int, [_ctx, C.c_char_p, C.c_char_p]),
     ("rtr_upload_scene", C.c_int, [_ctx, C.POINTER(rtr_scene_desc)]),
     ("rtr_scene_info_get", C.c_int, [_ctx, C.POINTER(rtr_scene_info)]),
     ("rtr_bvh_leaf_order", C.c_int64, [_ctx, C.POINTER(C.c_uint64), C.c_uint64]),

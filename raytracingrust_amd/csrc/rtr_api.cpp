@@ -37,6 +37,7 @@ struct rtr_context {
     int device = -1; // -1: host-only
     hipStream_t stream = nullptr;
     std::string error;
+    rtr::BuildOptions build_options;
     // scene
     bool have_scene = false;
     rtr::FlatScene flat; // host copy (kept for introspection)
@@ -280,7 +281,7 @@ int rtr_upload_scene(rtr_context *ctx, const rtr_scene_desc *scene) {
     auto t0 = std::chrono::steady_clock::now();
     rtr::FlatScene flat;
     std::string err;
-    int rc = rtr::build_flat_scene(*scene, flat, err);
+    int rc = rtr::build_flat_scene(*scene, flat, err, ctx->build_options);
     if (rc != RTR_OK) return fail(ctx, rc, err);
     if (ctx->device >= 0) {
         RTR_HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -300,6 +301,18 @@ int rtr_upload_scene(rtr_context *ctx, const rtr_scene_desc *scene) {
     ctx->have_scene = true;
     ctx->upload_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return RTR_OK;
+}
+
+int rtr_set_option(rtr_context *ctx, const char *name, const char *value) {
+    if (!ctx || !name || !value) return RTR_ERR_INVALID_ARGUMENT;
+    const std::string n(name), v(value);
+    if (n == "mesh_tree") { // takes effect at the next rtr_upload_scene
+        if (v == "reference") ctx->build_options.sah_mesh_trees = false;
+        else if (v == "sah") ctx->build_options.sah_mesh_trees = true;
+        else return fail(ctx, RTR_ERR_INVALID_ARGUMENT, "mesh_tree must be \"reference\" or \"sah\"");
+        return RTR_OK;
+    }
+    return fail(ctx, RTR_ERR_INVALID_ARGUMENT, "unknown option " + n);
 }
 
 int rtr_scene_info_get(const rtr_context *ctx, rtr_scene_info *out) {

@@ -13,6 +13,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
 
@@ -120,11 +121,98 @@ class Builder {
 };
 
 struct MeshBuild {
-    Tree tree;
+    Tree tree;                     // the reference's tree (mesh.rs:119-121): parity walk, and the leaf ranks
+    Tree fast;                     // optional: binned-SAH tree over the same triangle boxes (BuildOptions)
+    bool use_fast = false;
+    std::vector<uint32_t> rank;    // per triangle handle: its rank among the mesh's leaves in the REFERENCE tree's
+                                   // depth-first order -- exact-t ties resolve by it whichever tree is walked
     std::vector<DevLeafHot> hot;   // per triangle handle
     std::vector<DevLeafCold> cold; // per triangle handle
     Box bounds;                    // Mesh.bounds, mesh.rs:99-108
 };
+
+inline float half_area(const Box &b) {
+    float dx = b.mx[0] - b.mn[0], dy = b.mx[1] - b.mn[1], dz = b.mx[2] - b.mn[2];
+    return dx * dy + dy * dz + dz * dx;
+}
+
+// Binned surface-area-heuristic builder over the SAME leaf boxes (one triangle per leaf, so the node and leaf
+// formats are unchanged).  A different topology changes only how much of the tree a ray visits: the closest hit is
+// the same, exact-t ties are broken by reference rank, and the root box (the union of all leaf boxes) is identical.
+// Beyond `depth_limit` it splits by median so that the traversal stack (tree height) stays bounded.
+class SahBuilder {
+  public:
+    SahBuilder(const std::vector<Box> &bounds, Tree &tree, uint32_t depth_limit) : bounds_(bounds), tree_(tree), limit_(depth_limit) {}
+    int32_t build(std::vector<uint32_t> &h, size_t b, size_t e, uint32_t depth) {
+        int32_t id = (int32_t)tree_.nodes.size();
+        tree_.nodes.emplace_back();
+        size_t n = e - b;
+        if (n == 0) return id;
+        if (n == 1) { tree_.nodes[id].kind = T_LEAF; tree_.nodes[id].handle = h[b]; return id; }
+        Box all = bounds_[h[b]];
+        float cmin[3], cmax[3];
+        for (int k = 0; k < 3; k++) cmin[k] = cmax[k] = centroid(bounds_[h[b]], k);
+        for (size_t i = b + 1; i < e; i++) {
+            all = surround(all, bounds_[h[i]]);
+            for (int k = 0; k < 3; k++) { float c = centroid(bounds_[h[i]], k); cmin[k] = std::fmin(cmin[k], c); cmax[k] = std::fmax(cmax[k], c); }
+        }
+        size_t mid = b + n / 2;
+        int best_axis = -1;
+        float best_pos = 0.0f;
+        if (depth < limit_) {
+            constexpr int NB = 16;
+            float best_cost = INFINITY;
+            for (int ax = 0; ax < 3; ax++) {
+                float lo = cmin[ax], hi = cmax[ax];
+                if (!(hi > lo)) continue;
+                Box bb[NB]; uint32_t cnt[NB] = {0};
+                for (size_t i = b; i < e; i++) {
+                    int bi = std::min(NB - 1, (int)((centroid(bounds_[h[i]], ax) - lo) / (hi - lo) * NB));
+                    bb[bi] = cnt[bi] ? surround(bb[bi], bounds_[h[i]]) : bounds_[h[i]];
+                    cnt[bi]++;
+                }
+                for (int sp = 1; sp < NB; sp++) {
+                    Box L{}, R{}; uint32_t nl = 0, nr = 0;
+                    for (int i = 0; i < sp; i++) if (cnt[i]) { L = nl ? surround(L, bb[i]) : bb[i]; nl += cnt[i]; }
+                    for (int i = sp; i < NB; i++) if (cnt[i]) { R = nr ? surround(R, bb[i]) : bb[i]; nr += cnt[i]; }
+                    if (!nl || !nr) continue;
+                    float cost = half_area(L) * (float)nl + half_area(R) * (float)nr;
+                    if (cost < best_cost) { best_cost = cost; best_axis = ax; best_pos = lo + (hi - lo) * (float)sp / (float)NB; }
+                }
+            }
+        }
+        if (best_axis >= 0) {
+            auto it = std::stable_partition(h.begin() + (std::ptrdiff_t)b, h.begin() + (std::ptrdiff_t)e,
+                                            [&](uint32_t t) { return centroid(bounds_[t], best_axis) < best_pos; });
+            size_t m = (size_t)(it - h.begin());
+            if (m > b && m < e) mid = m;
+        } else { // median on the widest centroid axis (also the fallback below the depth limit)
+            int ax = 0;
+            for (int k = 1; k < 3; k++) if (cmax[k] - cmin[k] > cmax[ax] - cmin[ax]) ax = k;
+            std::stable_sort(h.begin() + (std::ptrdiff_t)b, h.begin() + (std::ptrdiff_t)e,
+                             [&](uint32_t p, uint32_t q) { return centroid(bounds_[p], ax) < centroid(bounds_[q], ax); });
+        }
+        int32_t l = build(h, b, mid, depth + 1);
+        int32_t r = build(h, mid, e, depth + 1);
+        TreeNode &nd = tree_.nodes[id];
+        nd.kind = T_SPLIT; nd.box = all; nd.left = l; nd.right = r;
+        return id;
+    }
+  private:
+    const std::vector<Box> &bounds_;
+    Tree &tree_;
+    uint32_t limit_;
+};
+
+void leaf_ranks(const Tree &t, int32_t ni, std::vector<uint32_t> &rank, uint32_t &next) {
+    const TreeNode &n = t.nodes[ni];
+    if (n.kind == T_LEAF) rank[n.handle] = next++;
+    else if (n.kind == T_SPLIT) { leaf_ranks(t, n.left, rank, next); leaf_ranks(t, n.right, rank, next); }
+}
+uint32_t tree_height(const Tree &t, int32_t ni) {
+    const TreeNode &n = t.nodes[ni];
+    return n.kind == T_SPLIT ? 1u + std::max(tree_height(t, n.left), tree_height(t, n.right)) : 0u;
+}
 
 inline void sub3(const float *a, const float *b, float *o) {
     o[0] = a[0] - b[0];
@@ -182,21 +270,22 @@ struct Flattener {
         return {REF_LEAF | L, Box{}, 0};
     }
 
-    Emitted emit_mesh_node(uint32_t object, const MeshBuild &mb, int32_t ni) {
-        const TreeNode &n = mb.tree.nodes[ni];
+    // Leaf records of a mesh occupy one block, ordered by REFERENCE depth-first rank whichever tree is flattened.
+    Emitted emit_mesh_node(uint32_t object, const MeshBuild &mb, const Tree &t, int32_t ni, uint32_t leaf_base) {
+        const TreeNode &n = t.nodes[ni];
         if (n.kind == T_NONE) return {REF_NONE, Box{}, 0};
         if (n.kind == T_LEAF) {
-            uint32_t L = (uint32_t)out.leaf_hot.size();
-            out.leaf_hot.push_back(mb.hot[n.handle]);
+            uint32_t L = leaf_base + mb.rank[n.handle];
+            out.leaf_hot[L] = mb.hot[n.handle];
             DevLeafCold c = mb.cold[n.handle];
             c.object = object;
-            out.leaf_cold.push_back(c);
+            out.leaf_cold[L] = c;
             return {REF_LEAF | REF_TRI | L, Box{}, 0};
         }
         uint32_t idx = (uint32_t)out.nodes.size();
         out.nodes.emplace_back();
-        Emitted l = emit_mesh_node(object, mb, n.left);
-        Emitted r = emit_mesh_node(object, mb, n.right);
+        Emitted l = emit_mesh_node(object, mb, t, n.left, leaf_base);
+        Emitted r = emit_mesh_node(object, mb, t, n.right, leaf_base);
         fill_node(idx, l, r);
         return {idx, n.box, 1 + std::max(l.height, r.height)};
     }
@@ -210,7 +299,11 @@ struct Flattener {
             e = emit_volume(object, desc.volumes[o.index]);
         } else {
             const MeshBuild &mb = meshes[o.index];
-            e = emit_mesh_node(object, mb, mb.tree.root); // Mesh::hit = bvh_root.hit, mesh.rs:124-127
+            const uint32_t leaf_base = (uint32_t)out.leaf_hot.size();
+            out.leaf_hot.resize(leaf_base + mb.hot.size());
+            out.leaf_cold.resize(leaf_base + mb.hot.size());
+            const Tree &t = mb.use_fast ? mb.fast : mb.tree;
+            e = emit_mesh_node(object, mb, t, t.root, leaf_base); // Mesh::hit = bvh_root.hit, mesh.rs:124-127
         }
         obj_ref[object] = e.ref;
         obj_box[object] = e.box;
@@ -245,7 +338,7 @@ struct Flattener {
 
 } // namespace
 
-int build_flat_scene(const rtr_scene_desc &desc, FlatScene &out, std::string &err) {
+int build_flat_scene(const rtr_scene_desc &desc, FlatScene &out, std::string &err, const BuildOptions &opts) {
     out = FlatScene{};
     if ((desc.n_objects && !desc.objects) || (desc.n_spheres && !desc.spheres) || (desc.n_meshes && !desc.meshes) ||
         (desc.n_materials && !desc.materials) || (desc.n_volumes && !desc.volumes)) {
@@ -336,6 +429,17 @@ int build_flat_scene(const rtr_scene_desc &desc, FlatScene &out, std::string &er
         Builder b(tb, mb.tree);
         mb.tree.root = b.build(handles, 0, handles.size());
         if (b.nan_seen) { err = "NaN triangle centroid: partial_cmp().unwrap() panics (bvh.rs:99,109,119)"; return RTR_ERR_NAN_CENTROID; }
+        mb.rank.assign(m.n_tris, 0u);
+        uint32_t next = 0;
+        leaf_ranks(mb.tree, mb.tree.root, mb.rank, next);
+        if (opts.sah_mesh_trees && m.n_tris > 2) {
+            std::iota(handles.begin(), handles.end(), 0u);
+            // SAH splits down to the balanced tree's height, median splits below: deeper SAH levels cost more LDS
+            // stack (occupancy) than they save (measured on house.obj / monkey.obj: limit +2..+30 and -2..-8 all slower)
+            SahBuilder sb(tb, mb.fast, tree_height(mb.tree, mb.tree.root));
+            mb.fast.root = sb.build(handles, 0, handles.size(), 0);
+            mb.use_fast = true;
+        }
     }
 
     // ---- scene-level collection (scene.rs:117-139) ----

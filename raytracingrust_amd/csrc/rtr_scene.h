@@ -33,8 +33,16 @@ struct FlatScene {
     uint32_t n_objects = 0, n_spheres = 0, n_meshes = 0, n_triangles = 0;
 };
 
+struct BuildOptions {
+    // false (default): every mesh subtree is the reference's median-split tree (Mesh::build_bvh, mesh.rs:119-121) --
+    // the parity configuration.  true: mesh subtrees are rebuilt with a binned surface-area heuristic over the same
+    // triangle boxes: same closest hits (ties still broken by reference rank), about half the traversal work on
+    // house.obj; frames can differ from the reference tree's in the ulp-level box-boundary cases of DESIGN.md section 3.
+    bool sah_mesh_trees = false;
+};
+
 // Returns RTR_OK or a negative rtr_status; on failure `err` holds the message.
-int build_flat_scene(const rtr_scene_desc &desc, FlatScene &out, std::string &err);
+int build_flat_scene(const rtr_scene_desc &desc, FlatScene &out, std::string &err, const BuildOptions &opts = BuildOptions());
 
 // RayOrigin of Camera::ray_origin (lib/core/camera.rs:37-56): origin, horizontal, vertical, lower_left_corner
 void camera_ray_origin(const rtr_camera &cam, float origin[3], float horizontal[3], float vertical[3], float llc[3]);

@@ -78,6 +78,10 @@ class Renderer:
         if rc != _capi.RTR_OK:
             raise _capi.RtrError(rc, (self._lib.rtr_last_error(self._ctx) or b"").decode())
 
+    def set_option(self, name: str, value: str) -> None:
+        """Context option, e.g. ("mesh_tree", "sah"); applied at the next upload_scene."""
+        self._check(self._lib.rtr_set_option(self._ctx, name.encode(), value.encode()))
+
     # -- scene -------------------------------------------------------------------------------------------
     def upload_scene(self, scene: Scene) -> None:
         lowered = LoweredScene(scene)

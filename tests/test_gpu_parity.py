@@ -396,3 +396,28 @@ def test_random_scenes(gpu_renderer, case):
     if finite:
         assert max(c["rel_l2"]) <= TOL, (case, c)
     assert c["mismatched_pixels"] <= (3 if with_mesh else 0), (case, c)
+
+
+@pytest.mark.parametrize("builder,w,h", [(lambda: house_scene(2), 192, 108), (lambda: monkey_scene(3), 160, 90),
+                                         (lambda: monkey_scene(2, material=rt.Dielectric(1.5), bvh=False), 96, 54)])
+def test_sah_mesh_trees_render_the_same_frame(builder, w, h):
+    """Option mesh_tree = "sah" (SURVEY 8f N1): mesh subtrees rebuilt with a surface-area heuristic.  The walk visits
+    about half the nodes but must find the same closest hits: same segment count as the oracle (no path changes
+    length), frame within tolerance, at most a handful of last-bit pixel differences (box-boundary cases)."""
+    scene = builder()
+    with rt.Renderer(0) as r:
+        r.set_option("mesh_tree", "sah")
+        r.upload_scene(scene)
+        rgba, mean = r.render(w, h, seed=12, want_rgba8=True, want_mean=True)
+        st = r.stats()
+        sah_height = r.scene_info().tree_height
+        r.set_option("mesh_tree", "reference")
+        r.upload_scene(scene)
+        assert r.scene_info().tree_height <= sah_height <= 2 * r.scene_info().tree_height  # depth-limited
+        with pytest.raises(rt.RtrError):
+            r.set_option("mesh_tree", "octree")
+    o_rgba, o_mean, o_st = pyoracle.OracleScene(scene).render(w, h, 12, threads=0)
+    c = compare(mean, rgba, o_mean, o_rgba)
+    assert st.segments == o_st.segments
+    assert max(c["rel_l2"]) <= TOL and c["max_u8_delta"] <= 1, c
+    assert c["mismatched_pixels"] <= 5, c
