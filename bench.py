@@ -91,6 +91,8 @@ def parse_args():
                          "grids of short waves, perfect balance) or 8x8 tiles round-robin (bit-identical to one GPU)")
     ap.add_argument("--mesh-tree", choices=["reference", "sah"], default="reference",
                     help="mesh subtrees: the reference's median split (parity) or the binned-SAH rebuild (faster walk)")
+    ap.add_argument("--scene-tree", choices=["reference", "sah"], default="reference",
+                    help="scene-level tree over the objects: the reference's median split (parity) or binned SAH")
     ap.add_argument("--pmc-traffic", type=float, default=None,
                     help="HBM bytes per launch from a separate rocprofv3 --pmc pass (profiles/), if collected")
     return ap.parse_args()
@@ -159,6 +161,7 @@ def main():
 
     r = rt.Renderer(local_rank)
     r.set_option("mesh_tree", args.mesh_tree)
+    r.set_option("scene_tree", args.scene_tree)
     r.upload_scene(scene)
     rgba8 = torch.zeros((H, W, 4), dtype=torch.uint8, device=dev)
     # N > 1: double-buffered integrate | RCCL reduce + resolve pipeline (raytracingrust_amd/distributed.py)

@@ -192,7 +192,9 @@ int rtr_abi_version(void);
  *               = "sah": mesh subtrees rebuilt with a binned surface-area heuristic over the same triangle boxes
  *                 (SURVEY section 8f N1).  Closest hits are the same and exact-t ties still resolve by the reference's
  *                 depth-first leaf rank; only ulp-level box-boundary cases can differ.  About half the traversal work
- *                 on assets/house.obj. */
+ *                 on assets/house.obj.
+ *   "scene_tree" = "reference" (default) | "sah": the same choice for the scene-level tree over the objects; honoured
+ *                 only for scenes without Volume objects whose object boxes all have positive extent. */
 int rtr_set_option(rtr_context *ctx, const char *name, const char *value);
 /* Lower + build + flatten + copy to HBM.  Replaces any previous scene of the context. */
 int rtr_upload_scene(rtr_context *ctx, const rtr_scene_desc *scene);

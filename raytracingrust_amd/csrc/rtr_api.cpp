@@ -312,6 +312,12 @@ int rtr_set_option(rtr_context *ctx, const char *name, const char *value) {
         else return fail(ctx, RTR_ERR_INVALID_ARGUMENT, "mesh_tree must be \"reference\" or \"sah\"");
         return RTR_OK;
     }
+    if (n == "scene_tree") {
+        if (v == "reference") ctx->build_options.sah_scene_tree = false;
+        else if (v == "sah") ctx->build_options.sah_scene_tree = true;
+        else return fail(ctx, RTR_ERR_INVALID_ARGUMENT, "scene_tree must be \"reference\" or \"sah\"");
+        return RTR_OK;
+    }
     return fail(ctx, RTR_ERR_INVALID_ARGUMENT, "unknown option " + n);
 }
 

@@ -233,6 +233,7 @@ struct Flattener {
     std::vector<uint32_t> &obj_ref;    // per object: ref of its leaf / subtree root
     std::vector<Box> &obj_box;         // per object: box of that root when it is a Split
     std::vector<uint32_t> &obj_height; // per object: Split nodes on its longest root-to-leaf path
+    const std::vector<uint32_t> &obj_leaf_base; // per object: first leaf slot = its rank block in the REFERENCE depth-first order
 
     // Box of a flattened ref's own Split node, needed by its parent.
     struct Emitted {
@@ -244,7 +245,7 @@ struct Flattener {
 
     // Volume (lib/volume.rs:19-32) over a sphere boundary: hot = boundary centre, radius, radius^2, -1/density
     Emitted emit_volume(uint32_t object, const rtr_volume &v) {
-        uint32_t L = (uint32_t)out.leaf_hot.size();
+        uint32_t L = obj_leaf_base[object];
         DevLeafHot hot{};
         const rtr_sphere &s = v.boundary;
         hot.f[0] = s.center[0]; hot.f[1] = s.center[1]; hot.f[2] = s.center[2]; hot.f[3] = s.radius;
@@ -252,21 +253,21 @@ struct Flattener {
         hot.f[5] = v.neg_inv_density;
         DevLeafCold cold{};
         cold.material = s.material; cold.object = object; cold.handle = 0; // Object::material = boundary.material(), volume.rs:98-100
-        out.leaf_hot.push_back(hot);
-        out.leaf_cold.push_back(cold);
+        out.leaf_hot[L] = hot;
+        out.leaf_cold[L] = cold;
         out.has_volumes = true;
         return {REF_LEAF | REF_VOL | L, Box{}, 0, true};
     }
 
     Emitted emit_sphere(uint32_t object, const rtr_sphere &s) {
-        uint32_t L = (uint32_t)out.leaf_hot.size();
+        uint32_t L = obj_leaf_base[object];
         DevLeafHot hot{};
         hot.f[0] = s.center[0]; hot.f[1] = s.center[1]; hot.f[2] = s.center[2]; hot.f[3] = s.radius;
         hot.f[4] = s.radius * s.radius; // objects.rs:27 `self.radius * self.radius`
         DevLeafCold cold{};
         cold.material = s.material; cold.object = object; cold.handle = 0;
-        out.leaf_hot.push_back(hot);
-        out.leaf_cold.push_back(cold);
+        out.leaf_hot[L] = hot;
+        out.leaf_cold[L] = cold;
         return {REF_LEAF | L, Box{}, 0};
     }
 
@@ -299,9 +300,7 @@ struct Flattener {
             e = emit_volume(object, desc.volumes[o.index]);
         } else {
             const MeshBuild &mb = meshes[o.index];
-            const uint32_t leaf_base = (uint32_t)out.leaf_hot.size();
-            out.leaf_hot.resize(leaf_base + mb.hot.size());
-            out.leaf_cold.resize(leaf_base + mb.hot.size());
+            const uint32_t leaf_base = obj_leaf_base[object];
             const Tree &t = mb.use_fast ? mb.fast : mb.tree;
             e = emit_mesh_node(object, mb, t, t.root, leaf_base); // Mesh::hit = bvh_root.hit, mesh.rs:124-127
         }
@@ -481,12 +480,54 @@ int build_flat_scene(const rtr_scene_desc &desc, FlatScene &out, std::string &er
         if (b.nan_seen) { err = "NaN object centroid: partial_cmp().unwrap() panics (bvh.rs:99,109,119)"; return RTR_ERR_NAN_CENTROID; }
     }
 
+    // Leaf slots: every object owns a block of leaf records, the blocks laid out in the reference scene tree's
+    // depth-first order, so a leaf's index is its reference rank whichever topology is walked.
+    std::vector<uint32_t> obj_leaf_base(desc.n_objects, 0u);
+    {
+        uint32_t next = 0;
+        std::vector<int32_t> todo{scene_tree.root};
+        while (!todo.empty()) { // explicit depth-first walk, left before right
+            int32_t ni = todo.back();
+            todo.pop_back();
+            const TreeNode &n = scene_tree.nodes[ni];
+            if (n.kind == T_LEAF) {
+                obj_leaf_base[n.handle] = next;
+                const rtr_object &o = desc.objects[n.handle];
+                next += o.kind == RTR_OBJ_MESH ? desc.meshes[o.index].n_tris : 1u;
+            } else if (n.kind == T_SPLIT) {
+                todo.push_back(n.right);
+                todo.push_back(n.left);
+            }
+        }
+        out.leaf_hot.assign(next, DevLeafHot{});
+        out.leaf_cold.assign(next, DevLeafCold{});
+    }
+    // Optional SAH topology for the scene-level tree (BuildOptions::sah_scene_tree): only when no Volume needs the
+    // reference's visit order and every object box has a positive extent on every axis (a zero-thickness union box
+    // never passes AABB::hit -- a quirk of the reference that regrouping objects would change visibly).
+    Tree scene_fast;
+    bool use_scene_fast = false;
+    if (opts.sah_scene_tree && desc.n_objects > 2 && desc.n_volumes == 0) {
+        bool solid = true;
+        for (const Box &b : ob)
+            for (int k = 0; k < 3; k++)
+                if (!(b.mx[k] > b.mn[k])) solid = false;
+        if (solid) {
+            std::vector<uint32_t> handles(desc.n_objects);
+            std::iota(handles.begin(), handles.end(), 0u);
+            SahBuilder sb(ob, scene_fast, tree_height(scene_tree, scene_tree.root));
+            scene_fast.root = sb.build(handles, 0, handles.size(), 0);
+            use_scene_fast = true;
+        }
+    }
+    const Tree &scene_walk = use_scene_fast ? scene_fast : scene_tree;
+
     // ---- flatten: preorder nodes, leaves ranked in the reference's depth-first order ----
     std::vector<uint32_t> obj_ref(desc.n_objects, REF_NONE);
     std::vector<Box> obj_box(desc.n_objects);
     std::vector<uint32_t> obj_height(desc.n_objects, 0);
-    Flattener fl{desc, meshes, scene_tree, out, obj_ref, obj_box, obj_height};
-    Flattener::Emitted root = fl.emit_scene_node(scene_tree.root);
+    Flattener fl{desc, meshes, scene_walk, out, obj_ref, obj_box, obj_height, obj_leaf_base};
+    Flattener::Emitted root = fl.emit_scene_node(scene_walk.root);
     out.root_ref = root.ref;
     for (int k = 0; k < 3; k++) { out.root_box[k] = root.box.mn[k]; out.root_box[3 + k] = root.box.mx[k]; }
     out.tree_height = root.height;

@@ -39,6 +39,9 @@ struct BuildOptions {
     // triangle boxes: same closest hits (ties still broken by reference rank), about half the traversal work on
     // house.obj; frames can differ from the reference tree's in the ulp-level box-boundary cases of DESIGN.md section 3.
     bool sah_mesh_trees = false;
+    // the same for the scene-level tree over the objects (used only for scenes without Volume objects whose object
+    // boxes all have positive extent; otherwise the reference tree is kept)
+    bool sah_scene_tree = false;
 };
 
 // Returns RTR_OK or a negative rtr_status; on failure `err` holds the message.

@@ -421,3 +421,25 @@ def test_sah_mesh_trees_render_the_same_frame(builder, w, h):
     assert st.segments == o_st.segments
     assert max(c["rel_l2"]) <= TOL and c["max_u8_delta"] <= 1, c
     assert c["mismatched_pixels"] <= 5, c
+
+
+def test_sah_scene_tree_renders_the_same_frame():
+    """Option scene_tree = "sah": the scene-level tree over simple.json's 102 spheres rebuilt with SAH.  Sphere boxes
+    are exact supersets in either tree, so the frame stays bit-identical apart from box-boundary grazes."""
+    scene = simple_scene(6)
+    w, h = 160, 160
+    with rt.Renderer(0) as r:
+        r.set_option("scene_tree", "sah")
+        r.upload_scene(scene)
+        rgba, mean = r.render(w, h, seed=3, want_rgba8=True, want_mean=True)
+        st = r.stats()
+    o_rgba, o_mean, o_st = pyoracle.OracleScene(scene).render(w, h, 3, threads=0)
+    c = compare(mean, rgba, o_mean, o_rgba)
+    assert st.segments == o_st.segments
+    assert max(c["rel_l2"]) <= TOL and c["max_u8_delta"] <= 1 and c["mismatched_pixels"] <= 3, c
+    # a scene with a Volume keeps the reference scene tree (its random draws depend on the visit order)
+    fog = _fog_scene(True, two_volumes=True)
+    with rt.Renderer(0) as r:
+        r.set_option("scene_tree", "sah")
+        c, st, o_st = run_both(r, fog, 64, 48, 9)
+    assert c["mismatched_pixels"] == 0 and st.segments == o_st.segments
