@@ -415,6 +415,8 @@ class Renderer {
     ~Renderer() { rtr_destroy(ctx_); }
     Renderer(const Renderer &) = delete;
     Renderer &operator=(const Renderer &) = delete;
+    // context options of include/rtr_hip.h, e.g. ("mesh_tree", "sah") / ("scene_tree", "sah"); applied at the next upload
+    void set_option(const std::string &name, const std::string &value) { check(rtr_set_option(ctx_, name.c_str(), value.c_str()), "rtr_set_option"); }
     void upload(const Scene &scene) {
         Lowered l; scene.lower(l);
         rtr_scene_desc d = l.desc();
