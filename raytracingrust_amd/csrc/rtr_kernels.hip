@@ -92,9 +92,6 @@ RTR_DEV V3 sample_unit_ball(Rng &rng, float &m2) {
         v.y = rng_signed(rng);
         v.z = rng_signed(rng);
         m2 = dot(v, v);
-#ifdef RTR_X_NOREJECT // timing experiment only (never defined in the product build): accept the first candidate
-        break;
-#endif
     } while (!(m2 <= 1.0f));
     return v;
 }
@@ -684,23 +681,12 @@ template <uint32_t WORLD, uint32_t NS, bool VOL>
 // 96 scalar registers: a wave's SGPRs come in 16-register granules out of 800 per SIMD, so the 105 the compiler would
 // take (sphere constants + camera + parameters) admit 7 waves per SIMD and 96 admit 8 -- the vector registers (62)
 // already allow 8.  Measured +2.4 % on the headline kernel, neutral on the tree kernels.
-#ifndef RTR_X_NUM_SGPR
-#define RTR_X_NUM_SGPR 96
-#endif
-__attribute__((amdgpu_num_sgpr(RTR_X_NUM_SGPR)))
+__attribute__((amdgpu_num_sgpr(96)))
 __global__ __launch_bounds__(64, RTR_X_WAVES_PER_EU) void k_render(const RenderParams p) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const uint32_t lane = threadIdx.x;
-#if defined(RTR_X_STRIDE) // timing experiment: scatter concurrently running tiles over the image
-    if (blockIdx.x * p.n_shards + p.shard >= p.tiles_total) return;
-    const uint32_t tile = (uint32_t)(((unsigned long long)(blockIdx.x * p.n_shards + p.shard) * RTR_X_STRIDE) % p.tiles_total);
-#elif defined(RTR_X_REVERSE) // timing experiment: bottom rows (geometry-heavy) first, sky tiles last
-    const uint32_t tile = p.tiles_total - 1u - (blockIdx.x * p.n_shards + p.shard);
-    if (tile >= p.tiles_total) return;
-#else
     const uint32_t tile = blockIdx.x * p.n_shards + p.shard;
     if (tile >= p.tiles_total) return;
-#endif
     uint32_t *chain = lds;
     uint32_t *stk_ref = lds + p.max_depth * 64u;
     float *stk_t = reinterpret_cast<float *>(stk_ref + p.stack_cap * 64u);
