@@ -8,6 +8,7 @@
 //   leaf_hot[]   48 B per leaf, indexed by the leaf's rank L in the reference's depth-first order
 //                (left before right, bvh.rs:162-163).  Sphere: centre, radius, radius^2.
 //                Triangle: v0, e1 = v1-v0, e2 = v2-v0 (mesh.rs:160-161, hoisted: pure functions).
+//                Volume: boundary centre, radius, radius^2, -1/density (volume.rs:19-32).
 //   leaf_cold[]  64 B per leaf, read once per segment for the winning leaf only: vertex normals,
 //                face normal (mesh.rs:86-90), material handle.
 //   lin_spheres[] 32 B per sphere in Scene.objects order: the linear world of scene.rs:141-157 when

@@ -1,0 +1,79 @@
+// Host-side sanity driver for csrc/rtr_scene.cpp (no HIP): lowers scenes through host/rtr.hpp, builds and flattens them
+// with every tree option, and checks structural invariants.  tests/test_host_sanitizers.py compiles it with
+// -fsanitize=address,undefined and runs it on the shipped meshes (the GPU box cannot run sanitizers on device code).
+#include <cstdio>
+#include <set>
+#include <string>
+
+#include "../../host/rtr.hpp"
+#include "../../raytracingrust_amd/csrc/rtr_scene.h"
+
+using namespace rtr;
+
+static int fails = 0;
+#define CHECK(c) do { if (!(c)) { std::printf("CHECK failed: %s (line %d)\n", #c, __LINE__); fails++; } } while (0)
+
+static void walk(const FlatScene &fs, uint32_t ref, std::set<uint32_t> &leaves, uint32_t depth, uint32_t &height) {
+    if (ref == REF_NONE) return;
+    if (ref & REF_LEAF) { CHECK(leaves.insert(ref & REF_INDEX).second); return; }
+    CHECK(ref < fs.nodes.size());
+    if (ref >= fs.nodes.size()) return;
+    height = std::max(height, depth + 1);
+    walk(fs, fs.nodes[ref].lref, leaves, depth + 1, height);
+    walk(fs, fs.nodes[ref].rref, leaves, depth + 1, height);
+}
+
+static void check_scene(const Scene &scene, const char *name) {
+    Lowered l;
+    scene.lower(l);
+    rtr_scene_desc d = l.desc();
+    for (int mode = 0; mode < 4; mode++) {
+        BuildOptions o;
+        o.sah_mesh_trees = mode & 1;
+        o.sah_scene_tree = mode & 2;
+        FlatScene fs;
+        std::string err;
+        int rc = build_flat_scene(d, fs, err, o);
+        CHECK(rc == RTR_OK);
+        if (rc != RTR_OK) { std::printf("%s: %s\n", name, err.c_str()); continue; }
+        std::set<uint32_t> leaves;
+        uint32_t height = 0;
+        walk(fs, fs.root_ref, leaves, 0, height);
+        CHECK(leaves.size() == fs.leaf_hot.size());          // every leaf reachable exactly once
+        CHECK(fs.leaf_hot.size() == fs.leaf_cold.size());
+        CHECK(height == fs.tree_height);                      // the traversal-stack bound is the real height
+        CHECK(fs.nodes.empty() || fs.nodes.size() + 1 >= fs.leaf_hot.size());
+        for (const DevLeafCold &c : fs.leaf_cold) CHECK(c.material < fs.materials.size() && c.object < fs.n_objects);
+        CHECK(fs.objects.size() == fs.n_objects);
+        std::printf("%-10s mode %d: nodes %zu leaves %zu height %u\n", name, mode, fs.nodes.size(), fs.leaf_hot.size(), fs.tree_height);
+    }
+}
+
+int main(int argc, char **argv) {
+    std::string data = argc > 1 ? argv[1] : "data";
+    check_scene(Scene::from_file(data + "/scenes/simple.json"), "simple");
+    check_scene(Scene::from_file(data + "/scenes/benchmark.json"), "benchmark");
+    {
+        Scene s; // meshes + spheres + a volume + nested mix materials
+        auto lam = s.add_material(std::make_unique<Lambertian>(Color{0.9f, 0.2f, 0.2f}));
+        auto mix = s.add_material(std::make_unique<MixMaterial>(
+            std::make_unique<Metal>(Color{0.1f, 0.1f, 0.1f}, 0.0f),
+            std::make_unique<MixMaterial>(std::make_unique<Lambertian>(Color{0.4f, 0.4f, 0.4f}), std::make_unique<Dielectric>(1.5f), 0.3f), 0.5f));
+        auto iso = s.add_material(std::make_unique<Isotropic>(Color{1, 1, 1}));
+        for (const char *m : {"house.obj", "plane.obj", "monkey.obj", "cube.obj", "cylinder.obj"})
+            s.add_object(Mesh::from_file(data + "/meshes/" + m, lam));
+        s.add_object(std::make_unique<Sphere>(Vec3{0.5f, 1.0f, 0.3f}, 0.7f, mix));
+        s.add_object(std::make_unique<Volume>(Sphere(Vec3{0, 0, 0}, 30.0f, iso), 0.1f));
+        s.add_object(Mesh::from_buffers({}, {}, {}, lam)); // empty mesh: BvhNode::None
+        check_scene(s, "mixed");
+    }
+    {
+        Scene s; // degenerate: empty, then a single object
+        check_scene(s, "empty");
+        auto lam = s.add_material(std::make_unique<Lambertian>(Color{0.5f, 0.5f, 0.5f}));
+        s.add_object(std::make_unique<Sphere>(Vec3{0, 0, -1}, 0.5f, lam));
+        check_scene(s, "single");
+    }
+    std::printf("%s\n", fails ? "FAILED" : "ok");
+    return fails != 0;
+}
