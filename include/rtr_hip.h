@@ -194,7 +194,11 @@ int rtr_abi_version(void);
  *                 depth-first leaf rank; only ulp-level box-boundary cases can differ.  About half the traversal work
  *                 on assets/house.obj.
  *   "scene_tree" = "reference" (default) | "sah": the same choice for the scene-level tree over the objects; honoured
- *                 only for scenes without Volume objects whose object boxes all have positive extent. */
+ *                 only for scenes without Volume objects whose object boxes all have positive extent.
+ *   "leaf_pairs" = "on" (default) | "off": a Split node whose two children are leaves of one type with consecutive
+ *                 ranks is stored inside its parent (same box test, same two leaf tests in the same order, one traversal
+ *                 step fewer).  Decisions are identical either way -- frames are bit-identical; "off" exists for A/B
+ *                 measurements. */
 int rtr_set_option(rtr_context *ctx, const char *name, const char *value);
 /* Lower + build + flatten + copy to HBM.  Replaces any previous scene of the context. */
 int rtr_upload_scene(rtr_context *ctx, const rtr_scene_desc *scene);

@@ -318,6 +318,12 @@ int rtr_set_option(rtr_context *ctx, const char *name, const char *value) {
         else return fail(ctx, RTR_ERR_INVALID_ARGUMENT, "scene_tree must be \"reference\" or \"sah\"");
         return RTR_OK;
     }
+    if (n == "leaf_pairs") {
+        if (v == "on") ctx->build_options.leaf_pairs = true;
+        else if (v == "off") ctx->build_options.leaf_pairs = false;
+        else return fail(ctx, RTR_ERR_INVALID_ARGUMENT, "leaf_pairs must be \"on\" or \"off\"");
+        return RTR_OK;
+    }
     return fail(ctx, RTR_ERR_INVALID_ARGUMENT, "unknown option " + n);
 }
 
@@ -328,7 +334,7 @@ int rtr_scene_info_get(const rtr_context *ctx, rtr_scene_info *out) {
     std::memset(out, 0, sizeof *out);
     out->n_objects = fs.n_objects; out->n_spheres = fs.n_spheres; out->n_meshes = fs.n_meshes;
     out->n_triangles = fs.n_triangles; out->n_materials = (uint32_t)fs.materials.size();
-    out->n_leaves = (uint32_t)fs.leaf_hot.size(); out->n_nodes = (uint32_t)fs.nodes.size();
+    out->n_leaves = (uint32_t)fs.leaf_hot.size(); out->n_nodes = fs.split_nodes;
     out->tree_height = fs.tree_height; out->spheres_only = fs.spheres_only ? 1u : 0u;
     out->device_bytes = ctx->device_bytes;
     return RTR_OK;

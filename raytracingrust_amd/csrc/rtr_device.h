@@ -26,7 +26,9 @@ constexpr uint32_t REF_NONE = 0xFFFFFFFFu;  // BvhNode::None
 constexpr uint32_t REF_LEAF = 0x80000000u;  // BvhNode::Object
 constexpr uint32_t REF_TRI = 0x40000000u;   // leaf is a triangle
 constexpr uint32_t REF_VOL = 0x20000000u;   // leaf is a Volume (lib/volume.rs); neither bit: sphere
-constexpr uint32_t REF_INDEX = 0x1FFFFFFFu; // leaf rank L, or node index
+constexpr uint32_t REF_PAIR = 0x10000000u;  // leaf ref only: a collapsed Split of the two leaves L and L+1 (same
+                                            // type), gated by the Split's box like an inner node
+constexpr uint32_t REF_INDEX = 0x0FFFFFFFu; // leaf rank L, or node index
 
 constexpr uint32_t NODE_LVOL = 1u; // the left / right subtree holds a Volume leaf: Volume::hit draws a random
 constexpr uint32_t NODE_RVOL = 2u; // number on every visit, so such subtrees are never culled nor reordered

@@ -338,8 +338,11 @@ RTR_DEV void traverse(const RenderParams &p, uint32_t root, const Ray &r, V3 inv
         if (cur == REF_NONE) {
             pop = true;
         } else if (cur & REF_LEAF) {
-            test_leaf<VOL>(p, cur, r, a, best, rng);
-            pop = true;
+            // a REF_PAIR ref stands for Split(leaf L, leaf L+1), its box already tested where the ref was read
+            // (Both triangles of a pair in one 96-byte gather was measured no faster: +13 VGPRs.)
+            test_leaf<VOL>(p, cur & ~REF_PAIR, r, a, best, rng);
+            pop = !(cur & REF_PAIR);
+            cur = (cur & ~REF_PAIR) + 1u; // the pair's second leaf: the next trip, no stack traffic
         } else {
             const float4 *nq = reinterpret_cast<const float4 *>(p.nodes + cur);
             float4 q0 = nq[0], q1 = nq[1], q2 = nq[2], q3 = nq[3];
@@ -353,11 +356,11 @@ RTR_DEV void traverse(const RenderParams &p, uint32_t root, const Ray &r, V3 inv
             const bool lvol = VOL && (flags & NODE_LVOL), rvol = VOL && (flags & NODE_RVOL);
             bool hl = l != REF_NONE, hr = rr != REF_NONE;
             float el = 0.0f, er = 0.0f;
-            if (hl && !(l & REF_LEAF)) {
+            if (hl && (l & (REF_LEAF | REF_PAIR)) != REF_LEAF) { // Split nodes and collapsed leaf pairs carry a box
                 hl = slab(lmin, lmax, r, inv, tmax_box, el);
                 if (!lvol && el > best.t) hl = false; // best.t is +inf until a leaf is hit
             }
-            if (hr && !(rr & REF_LEAF)) {
+            if (hr && (rr & (REF_LEAF | REF_PAIR)) != REF_LEAF) {
                 hr = slab(rmin, rmax, r, inv, tmax_box, er);
                 if (!rvol && er > best.t) hr = false;
             }
@@ -569,7 +572,7 @@ RTR_DEV bool world_hit(const RenderParams &p, const Ray &r, Hit &h, uint32_t *st
         if constexpr (WORLD == WORLD_BVH) {
             uint32_t root = p.root_ref;
             bool go = root != REF_NONE;
-            if (go && !(root & REF_LEAF)) {
+            if (go && (root & (REF_LEAF | REF_PAIR)) != REF_LEAF) {
                 float e;
                 go = slab(p.root_box, p.root_box + 3, r, inv, __builtin_inff(), e);
             }
@@ -596,7 +599,7 @@ RTR_DEV bool world_hit(const RenderParams &p, const Ray &r, Hit &h, uint32_t *st
                     Best local;
                     local.leaf = REF_NONE; local.t = __builtin_inff(); local.u = 0.0f; local.v = 0.0f;
                     bool go = true;
-                    if (!(ref & REF_LEAF)) {
+                    if ((ref & (REF_LEAF | REF_PAIR)) != REF_LEAF) {
                         float e;
                         go = slab(o.box, o.box + 3, r, inv, closest, e);
                     }

@@ -234,6 +234,7 @@ struct Flattener {
     std::vector<Box> &obj_box;         // per object: box of that root when it is a Split
     std::vector<uint32_t> &obj_height; // per object: Split nodes on its longest root-to-leaf path
     const std::vector<uint32_t> &obj_leaf_base; // per object: first leaf slot = its rank block in the REFERENCE depth-first order
+    bool leaf_pairs = true;
 
     // Box of a flattened ref's own Split node, needed by its parent.
     struct Emitted {
@@ -283,6 +284,14 @@ struct Flattener {
             out.leaf_cold[L] = c;
             return {REF_LEAF | REF_TRI | L, Box{}, 0};
         }
+        out.split_nodes++;
+        if (leaf_pairs && t.nodes[n.left].kind == T_LEAF && t.nodes[n.right].kind == T_LEAF &&
+            mb.rank[t.nodes[n.right].handle] == mb.rank[t.nodes[n.left].handle] + 1u) {
+            // Split(triangle L, triangle L+1): no node record, the parent gates the pair with this Split's box
+            Emitted l = emit_mesh_node(object, mb, t, n.left, leaf_base);
+            emit_mesh_node(object, mb, t, n.right, leaf_base);
+            return {l.ref | REF_PAIR, n.box, 1};
+        }
         uint32_t idx = (uint32_t)out.nodes.size();
         out.nodes.emplace_back();
         Emitted l = emit_mesh_node(object, mb, t, n.left, leaf_base);
@@ -310,10 +319,22 @@ struct Flattener {
         return e;
     }
 
+    bool is_sphere_leaf(int32_t ni) const {
+        const TreeNode &n = scene_tree.nodes[ni];
+        return n.kind == T_LEAF && desc.objects[n.handle].kind == RTR_OBJ_SPHERE;
+    }
+
     Emitted emit_scene_node(int32_t ni) {
         const TreeNode &n = scene_tree.nodes[ni];
         if (n.kind == T_NONE) return {REF_NONE, Box{}, 0};
         if (n.kind == T_LEAF) return emit_object(n.handle);
+        out.split_nodes++;
+        if (leaf_pairs && is_sphere_leaf(n.left) && is_sphere_leaf(n.right) &&
+            obj_leaf_base[scene_tree.nodes[n.right].handle] == obj_leaf_base[scene_tree.nodes[n.left].handle] + 1u) {
+            Emitted l = emit_scene_node(n.left); // Split(sphere L, sphere L+1)
+            emit_scene_node(n.right);
+            return {l.ref | REF_PAIR, n.box, 1};
+        }
         uint32_t idx = (uint32_t)out.nodes.size();
         out.nodes.emplace_back();
         Emitted l = emit_scene_node(n.left);
@@ -527,6 +548,7 @@ int build_flat_scene(const rtr_scene_desc &desc, FlatScene &out, std::string &er
     std::vector<Box> obj_box(desc.n_objects);
     std::vector<uint32_t> obj_height(desc.n_objects, 0);
     Flattener fl{desc, meshes, scene_walk, out, obj_ref, obj_box, obj_height, obj_leaf_base};
+    fl.leaf_pairs = opts.leaf_pairs;
     Flattener::Emitted root = fl.emit_scene_node(scene_walk.root);
     out.root_ref = root.ref;
     for (int k = 0; k < 3; k++) { out.root_box[k] = root.box.mn[k]; out.root_box[3 + k] = root.box.mx[k]; }

@@ -26,6 +26,7 @@ struct FlatScene {
     float bg_a[3] = {0, 0, 0}, bg_b[3] = {0, 0, 0};
     uint32_t root_ref = REF_NONE;
     float root_box[6] = {0, 0, 0, 0, 0, 0};
+    uint32_t split_nodes = 0;   // Split nodes of the flattened trees, collapsed leaf pairs included
     uint32_t tree_height = 0;   // Split nodes on the longest root-to-leaf path of the scene tree
     uint32_t mesh_height = 0;   // same, over the mesh subtrees alone (linear world with meshes)
     bool spheres_only = true;
@@ -42,6 +43,10 @@ struct BuildOptions {
     // the same for the scene-level tree over the objects (used only for scenes without Volume objects whose object
     // boxes all have positive extent; otherwise the reference tree is kept)
     bool sah_scene_tree = false;
+    // A Split whose children are two leaves of one type with consecutive ranks is stored in its parent as one
+    // REF_PAIR ref (no node record): the same box test, the same two leaf tests in the same order, one
+    // traversal step fewer.  Decisions are unchanged, so this stays on in the parity configuration.
+    bool leaf_pairs = true;
 };
 
 // Returns RTR_OK or a negative rtr_status; on failure `err` holds the message.

@@ -34,11 +34,14 @@ def main():
     ap.add_argument("--spp", type=int, default=32)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--oracle-size", default="96x54")
+    ap.add_argument("--options", default="", help="comma-separated name=value pairs for rtr_set_option (e.g. mesh_tree=sah)")
     args = ap.parse_args()
     import pyoracle
 
     ow, oh = (int(v) for v in args.oracle_size.split("x"))
     r = rt.Renderer(0)
+    for kv in filter(None, args.options.split(",")):
+        r.set_option(*kv.split("=", 1))
     for name in args.configs.split(","):
         scene, W, H = build(name, args.spp)
         t0 = time.perf_counter()

@@ -15,7 +15,14 @@ static int fails = 0;
 
 static void walk(const FlatScene &fs, uint32_t ref, std::set<uint32_t> &leaves, uint32_t depth, uint32_t &height) {
     if (ref == REF_NONE) return;
-    if (ref & REF_LEAF) { CHECK(leaves.insert(ref & REF_INDEX).second); return; }
+    if (ref & REF_LEAF) {
+        CHECK(leaves.insert(ref & REF_INDEX).second);
+        if (ref & REF_PAIR) { // a collapsed Split of two leaves: counts as one level
+            CHECK(leaves.insert((ref & REF_INDEX) + 1).second);
+            height = std::max(height, depth + 1);
+        }
+        return;
+    }
     CHECK(ref < fs.nodes.size());
     if (ref >= fs.nodes.size()) return;
     height = std::max(height, depth + 1);
@@ -27,10 +34,11 @@ static void check_scene(const Scene &scene, const char *name) {
     Lowered l;
     scene.lower(l);
     rtr_scene_desc d = l.desc();
-    for (int mode = 0; mode < 4; mode++) {
+    for (int mode = 0; mode < 8; mode++) {
         BuildOptions o;
         o.sah_mesh_trees = mode & 1;
         o.sah_scene_tree = mode & 2;
+        o.leaf_pairs = !(mode & 4);
         FlatScene fs;
         std::string err;
         int rc = build_flat_scene(d, fs, err, o);
@@ -42,7 +50,8 @@ static void check_scene(const Scene &scene, const char *name) {
         CHECK(leaves.size() == fs.leaf_hot.size());          // every leaf reachable exactly once
         CHECK(fs.leaf_hot.size() == fs.leaf_cold.size());
         CHECK(height == fs.tree_height);                      // the traversal-stack bound is the real height
-        CHECK(fs.nodes.empty() || fs.nodes.size() + 1 >= fs.leaf_hot.size());
+        CHECK(fs.split_nodes == 0 || fs.split_nodes + 1 >= fs.leaf_hot.size());
+        CHECK(o.leaf_pairs ? fs.nodes.size() <= fs.split_nodes : fs.nodes.size() == fs.split_nodes);
         for (const DevLeafCold &c : fs.leaf_cold) CHECK(c.material < fs.materials.size() && c.object < fs.n_objects);
         CHECK(fs.objects.size() == fs.n_objects);
         std::printf("%-10s mode %d: nodes %zu leaves %zu height %u\n", name, mode, fs.nodes.size(), fs.leaf_hot.size(), fs.tree_height);

@@ -423,6 +423,33 @@ def test_sah_mesh_trees_render_the_same_frame(builder, w, h):
     assert c["mismatched_pixels"] <= 5, c
 
 
+@pytest.mark.parametrize("builder,w,h", [(lambda: house_scene(2), 160, 90), (lambda: simple_scene(4), 128, 128),
+                                         (lambda: monkey_scene(2, bvh=False), 96, 54),
+                                         (lambda: benchmark_scene(4, enable_bvh_tree=True), 128, 72)])
+def test_leaf_pairs_do_not_change_a_bit(builder, w, h):
+    """Option leaf_pairs (default "on") folds Split(leaf L, leaf L+1) nodes into their parents: the same box and leaf
+    tests in the same order, so the frame must be bit-identical to the unfolded tree's and to the oracle's."""
+    scene = builder()
+    with rt.Renderer(0) as r:
+        r.upload_scene(scene)
+        nodes_on = r.scene_info().n_nodes
+        rgba_on, mean_on = r.render(w, h, seed=21, want_rgba8=True, want_mean=True)
+        seg_on = r.stats().segments
+        r.set_option("leaf_pairs", "off")
+        r.upload_scene(scene)
+        assert r.scene_info().n_nodes == nodes_on  # scene_info reports the reference's Split count either way
+        rgba_off, mean_off = r.render(w, h, seed=21, want_rgba8=True, want_mean=True)
+        assert r.stats().segments == seg_on
+        with pytest.raises(rt.RtrError):
+            r.set_option("leaf_pairs", "maybe")
+    assert np.array_equal(rgba_on, rgba_off)
+    assert np.array_equal(mean_on.view(np.uint32), mean_off.view(np.uint32))
+    o_rgba, o_mean, o_st = pyoracle.OracleScene(scene).render(w, h, 21, threads=0)
+    assert o_st.segments == seg_on
+    c = compare(mean_on, rgba_on, o_mean, o_rgba)
+    assert max(c["rel_l2"]) <= TOL and c["max_u8_delta"] <= 1, c
+
+
 def test_sah_scene_tree_renders_the_same_frame():
     """Option scene_tree = "sah": the scene-level tree over simple.json's 102 spheres rebuilt with SAH.  Sphere boxes
     are exact supersets in either tree, so the frame stays bit-identical apart from box-boundary grazes."""
