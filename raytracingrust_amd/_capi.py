@@ -132,6 +132,13 @@ def load():
         raise ImportError(
             f"{path} is missing: the HIP extension has not been built (python -m raytracingrust_amd.build). "
             "raytracingrust_amd has no CPU fallback.")
+    # PyTorch-ROCm wheels bundle their own HIP/HSA runtime.  Whichever of torch and this library is loaded first
+    # decides which copy the process initialises, and torch finds no GPU when ours came first -- so when torch is
+    # installed (it carries the streams / RCCL plumbing of distributed.py and bench.py) it goes first.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(path)
     for name, restype, argtypes in SYMBOLS:
         fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
