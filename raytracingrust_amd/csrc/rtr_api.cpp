@@ -50,7 +50,6 @@ struct rtr_context {
     hipEvent_t ev_res_start = nullptr, ev_res_stop = nullptr;
     bool resolve_timed = false;
     unsigned long long *d_counters = nullptr; // kRing slots
-    uint32_t *d_error_flag = nullptr;
     uint32_t launches = 0;
     uint64_t last_primary = 0;
     uint32_t last_lds = 0, last_vgprs = 0;
@@ -139,6 +138,7 @@ int launch_frame(rtr_context *ctx, const rtr_camera *camera, const rtr_settings 
     else { p.world = rtr::WORLD_LINEAR_GENERIC; p.stack_cap = fs.mesh_height + 1u; }
     p.n_objects = fs.n_objects;
     p.has_volumes = fs.has_volumes ? 1u : 0u;
+    p.has_meshes = fs.n_triangles > 0u ? 1u : 0u;
     p.root_ref = fs.root_ref;
     std::memcpy(p.root_box, fs.root_box, sizeof p.root_box);
     p.nodes = static_cast<const rtr::DevNode *>(ctx->d_nodes);
@@ -160,7 +160,6 @@ int launch_frame(rtr_context *ctx, const rtr_camera *camera, const rtr_settings 
     p.sum_rgba = d_sum_rgba; p.rgba8 = d_rgba8; p.mean_rgb = d_mean_rgb;
     const uint32_t slot = ctx->launches % kRing;
     p.counter = ctx->d_counters + slot;
-    p.error_flag = ctx->d_error_flag;
 
     uint32_t grid = p.tiles_total > shard ? (p.tiles_total - shard + n_shards - 1u) / n_shards : 0u;
     // small tables staged in LDS: the linear sphere world's records, and the materials when they fit 4 KB
@@ -246,8 +245,6 @@ int rtr_create(int device, rtr_context **out) {
     if ((e = hipEventCreate(&ctx->ev_res_stop)) != hipSuccess) return bail(e, "hipEventCreate");
     if ((e = hipMalloc((void **)&ctx->d_counters, kRing * sizeof(unsigned long long))) != hipSuccess) return bail(e, "hipMalloc");
     if ((e = hipMemset(ctx->d_counters, 0, kRing * sizeof(unsigned long long))) != hipSuccess) return bail(e, "hipMemset");
-    if ((e = hipMalloc((void **)&ctx->d_error_flag, sizeof(uint32_t))) != hipSuccess) return bail(e, "hipMalloc");
-    if ((e = hipMemset(ctx->d_error_flag, 0, sizeof(uint32_t))) != hipSuccess) return bail(e, "hipMemset");
     *out = ctx;
     return RTR_OK;
 }
@@ -265,7 +262,6 @@ void rtr_destroy(rtr_context *ctx) {
         if (ctx->ev_res_start) (void)hipEventDestroy(ctx->ev_res_start);
         if (ctx->ev_res_stop) (void)hipEventDestroy(ctx->ev_res_stop);
         if (ctx->d_counters) (void)hipFree(ctx->d_counters);
-        if (ctx->d_error_flag) (void)hipFree(ctx->d_error_flag);
         if (ctx->d_rgba8) (void)hipFree(ctx->d_rgba8);
         if (ctx->d_mean) (void)hipFree(ctx->d_mean);
         if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -411,9 +407,6 @@ int rtr_render(rtr_context *ctx, const rtr_camera *camera, const rtr_settings *s
     if (rgba8) RTR_HIP_TRY(ctx, hipMemcpyAsync(rgba8, d8, npx * 4, hipMemcpyDeviceToHost, ctx->stream));
     if (mean_rgb) RTR_HIP_TRY(ctx, hipMemcpyAsync(mean_rgb, dm, npx * 3 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     RTR_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    uint32_t flag = 0;
-    RTR_HIP_TRY(ctx, hipMemcpy(&flag, ctx->d_error_flag, sizeof flag, hipMemcpyDeviceToHost));
-    if (flag) return fail(ctx, RTR_ERR_HIP, "traversal stack overflow on the device (internal error)");
     return RTR_OK;
 }
 

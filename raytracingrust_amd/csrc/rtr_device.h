@@ -96,6 +96,7 @@ struct RenderParams {
     uint32_t stack_cap; // entries per lane
     uint32_t sphere_regs;   // linear sphere world: spheres held in scalar registers (0 = generic loop)
     uint32_t lds_materials; // number of material records staged in LDS (0 = read from HBM/L1)
+    uint32_t has_meshes;    // the scene holds triangles: tree kernels instantiated with the unconditional slab tests
     uint32_t has_volumes;   // the scene holds Volume objects: kernels instantiated with the visit-order rules
     const DevNode *nodes;
     const DevLeafHot *leaf_hot;
@@ -116,7 +117,6 @@ struct RenderParams {
     uint8_t *rgba8;              // fused path or nullptr
     float *mean_rgb;             // fused path, optional
     unsigned long long *counter; // segments
-    uint32_t *error_flag;        // set non-zero on traversal-stack overflow (never expected)
 };
 
 } // namespace rtr

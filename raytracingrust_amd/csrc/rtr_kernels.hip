@@ -326,7 +326,7 @@ RTR_DEV void test_leaf(const RenderParams &p, uint32_t ref, const Ray &r, float 
 // strictly beyond the best hit so far -- nothing inside it can win or tie.
 // tmax_box is the tmax the reference hands to AABB::hit: +inf from the scene tree, closest_so_far when a
 // mesh is reached from the linear world (scene.rs:147, mesh.rs:124-127).
-template <bool VOL>
+template <bool VOL, bool MESH>
 RTR_DEV void traverse(const RenderParams &p, uint32_t root, const Ray &r, V3 inv, float a, float tmax_box,
                       Best &best, uint32_t *stk_ref, float *stk_t, uint32_t lane, Rng &rng) {
     // Volume leaves draw a random number on every visit (volume.rs:57), so a subtree that holds one is visited
@@ -335,9 +335,8 @@ RTR_DEV void traverse(const RenderParams &p, uint32_t root, const Ray &r, V3 inv
     uint32_t cur = root;
     for (;;) {
         bool pop = false;
-        if (cur == REF_NONE) {
-            pop = true;
-        } else if (cur & REF_LEAF) {
+        // (cur is never REF_NONE here: the callers test the root, a node step tests both children before descending)
+        if (cur & REF_LEAF) {
             // a REF_PAIR ref stands for Split(leaf L, leaf L+1), its box already tested where the ref was read
             // (Both triangles of a pair in one 96-byte gather was measured no faster: +13 VGPRs.)
             test_leaf<VOL>(p, cur & ~REF_PAIR, r, a, best, rng);
@@ -356,13 +355,28 @@ RTR_DEV void traverse(const RenderParams &p, uint32_t root, const Ray &r, V3 inv
             const bool lvol = VOL && (flags & NODE_LVOL), rvol = VOL && (flags & NODE_RVOL);
             bool hl = l != REF_NONE, hr = rr != REF_NONE;
             float el = 0.0f, er = 0.0f;
-            if (hl && (l & (REF_LEAF | REF_PAIR)) != REF_LEAF) { // Split nodes and collapsed leaf pairs carry a box
-                hl = slab(lmin, lmax, r, inv, tmax_box, el);
-                if (!lvol && el > best.t) hl = false; // best.t is +inf until a leaf is hit
-            }
-            if (hr && (rr & (REF_LEAF | REF_PAIR)) != REF_LEAF) {
-                hr = slab(rmin, rmax, r, inv, tmax_box, er);
-                if (!rvol && er > best.t) hr = false;
+            if constexpr (MESH) {
+                // Mesh scenes: nearly every child is a Split node or a leaf pair, i.e. carries a box.  Both slab tests
+                // run unconditionally, side by side -- straight-line code instead of two exec-mask regions
+                // (+2 ... +8 % on C3/C4; on sphere scenes, where half the children are bare leaves, it loses 4 %).
+                float tl, tr;
+                const bool sl = slab(lmin, lmax, r, inv, tmax_box, tl);
+                const bool sr = slab(rmin, rmax, r, inv, tmax_box, tr);
+                const bool gl = (l & (REF_LEAF | REF_PAIR)) != REF_LEAF; // Split nodes and collapsed leaf pairs carry a box
+                const bool gr = (rr & (REF_LEAF | REF_PAIR)) != REF_LEAF;
+                el = gl ? tl : 0.0f;
+                er = gr ? tr : 0.0f;
+                hl = hl && (!gl || (sl && (lvol || !(tl > best.t)))); // best.t is +inf until a leaf is hit
+                hr = hr && (!gr || (sr && (rvol || !(tr > best.t))));
+            } else {
+                if (hl && (l & (REF_LEAF | REF_PAIR)) != REF_LEAF) {
+                    hl = slab(lmin, lmax, r, inv, tmax_box, el);
+                    if (!lvol && el > best.t) hl = false;
+                }
+                if (hr && (rr & (REF_LEAF | REF_PAIR)) != REF_LEAF) {
+                    hr = slab(rmin, rmax, r, inv, tmax_box, er);
+                    if (!rvol && er > best.t) hr = false;
+                }
             }
             if (hl && hr) {
                 bool sw = er < el;
@@ -371,13 +385,11 @@ RTR_DEV void traverse(const RenderParams &p, uint32_t root, const Ray &r, V3 inv
                 float esecond = sw ? el : er;
                 if (sw ? lvol : rvol) esecond = -__builtin_inff(); // never culled at pop time
                 cur = sw ? rr : l;
-                if (sp < p.stack_cap) {
-                    stk_ref[sp * 64 + lane] = second;
-                    stk_t[sp * 64 + lane] = esecond;
-                    sp++;
-                } else {
-                    *p.error_flag = 1u;
-                }
+                // One push per Split node on the path: sp <= tree height < p.stack_cap, by construction of the flattener
+                // (checked on the host by tests/cpp/scene_sanity.cpp); an explicit bound test here cost 1-4 %.
+                stk_ref[sp * 64 + lane] = second;
+                stk_t[sp * 64 + lane] = esecond;
+                sp++;
             } else if (hl) {
                 cur = l;
             } else if (hr) {
@@ -452,7 +464,7 @@ struct SphereRegs {
 };
 
 // world.hit (render.rs:38).  Returns false on miss.
-template <uint32_t WORLD, uint32_t NS, bool VOL>
+template <uint32_t WORLD, uint32_t NS, bool VOL, bool MESH>
 RTR_DEV bool world_hit(const RenderParams &p, const Ray &r, Hit &h, uint32_t *stk_ref, float *stk_t, uint32_t lane,
                        const SphereRegs<NS> &sr, const uint32_t *lds_spheres, Rng &rng) {
     const float a = dot(r.d, r.d); // objects.rs:25, hoisted per ray
@@ -576,7 +588,7 @@ RTR_DEV bool world_hit(const RenderParams &p, const Ray &r, Hit &h, uint32_t *st
                 float e;
                 go = slab(p.root_box, p.root_box + 3, r, inv, __builtin_inff(), e);
             }
-            if (go) traverse<VOL>(p, root, r, inv, a, __builtin_inff(), best, stk_ref, stk_t, lane, rng);
+            if (go) traverse<VOL, MESH>(p, root, r, inv, a, __builtin_inff(), best, stk_ref, stk_t, lane, rng);
         } else {
             // scene.rs:141-157 with meshes: object.hit(ray, tmin, closest_so_far); a mesh returns the nearest
             // triangle of the boxes that pass AABB::hit(.., closest_so_far) and Triangle::hit ignores tmax
@@ -603,7 +615,7 @@ RTR_DEV bool world_hit(const RenderParams &p, const Ray &r, Hit &h, uint32_t *st
                         float e;
                         go = slab(o.box, o.box + 3, r, inv, closest, e);
                     }
-                    if (go) traverse<VOL>(p, ref, r, inv, a, closest, local, stk_ref, stk_t, lane, rng);
+                    if (go) traverse<VOL, true>(p, ref, r, inv, a, closest, local, stk_ref, stk_t, lane, rng);
                     if (local.leaf != REF_NONE) {
                         closest = local.t;
                         best = local;
@@ -680,7 +692,7 @@ RTR_DEV V3 background(const RenderParams &p, const Ray &r) {
 #ifndef RTR_X_WAVES_PER_EU
 #define RTR_X_WAVES_PER_EU 1
 #endif
-template <uint32_t WORLD, uint32_t NS, bool VOL>
+template <uint32_t WORLD, uint32_t NS, bool VOL, bool MESH>
 // 96 scalar registers: a wave's SGPRs come in 16-register granules out of 800 per SIMD, so the 105 the compiler would
 // take (sphere constants + camera + parameters) admit 7 waves per SIMD and 96 admit 8 -- the vector registers (62)
 // already allow 8.  Measured +2.4 % on the headline kernel, neutral on the tree kernels.
@@ -767,7 +779,7 @@ __global__ __launch_bounds__(64, RTR_X_WAVES_PER_EU) void k_render(const RenderP
 #endif
         bool done;
         V3 term;
-        const bool was_hit = world_hit<WORLD, NS, VOL>(p, ray, h, stk_ref, stk_t, lane, sr, lds_spheres, rng);
+        const bool was_hit = world_hit<WORLD, NS, VOL, MESH>(p, ray, h, stk_ref, stk_t, lane, sr, lds_spheres, rng);
         RTR_STAMP(0)
         if (!was_hit) {
             term = background(p, ray);
@@ -943,7 +955,7 @@ hipError_t launch_selftest_sqrt(unsigned long long *d_mismatches, hipStream_t st
 // --- launchers (called from rtr_api.cpp) -----------------------------------------------------------------
 template <uint32_t NS>
 static void launch_spheres(const RenderParams &p, uint32_t grid, uint32_t lds_bytes, hipStream_t stream) {
-    hipLaunchKernelGGL((k_render<WORLD_LINEAR_SPHERES, NS, false>), dim3(grid), dim3(64), lds_bytes, stream, p);
+    hipLaunchKernelGGL((k_render<WORLD_LINEAR_SPHERES, NS, false, false>), dim3(grid), dim3(64), lds_bytes, stream, p);
 }
 
 hipError_t launch_render(const RenderParams &p, uint32_t grid, uint32_t lds_bytes, hipStream_t stream) {
@@ -962,12 +974,15 @@ hipError_t launch_render(const RenderParams &p, uint32_t grid, uint32_t lds_byte
         }
         break;
     case WORLD_BVH: // Volume leaves need the reference's visit set and order: a separate instantiation pays for it
-        if (p.has_volumes) hipLaunchKernelGGL((k_render<WORLD_BVH, 0, true>), dim3(grid), dim3(64), lds_bytes, stream, p);
-        else hipLaunchKernelGGL((k_render<WORLD_BVH, 0, false>), dim3(grid), dim3(64), lds_bytes, stream, p);
+        // ... and scenes with meshes get the traversal with unconditional slab tests (see `traverse`)
+        if (p.has_volumes && p.has_meshes) hipLaunchKernelGGL((k_render<WORLD_BVH, 0, true, true>), dim3(grid), dim3(64), lds_bytes, stream, p);
+        else if (p.has_volumes) hipLaunchKernelGGL((k_render<WORLD_BVH, 0, true, false>), dim3(grid), dim3(64), lds_bytes, stream, p);
+        else if (p.has_meshes) hipLaunchKernelGGL((k_render<WORLD_BVH, 0, false, true>), dim3(grid), dim3(64), lds_bytes, stream, p);
+        else hipLaunchKernelGGL((k_render<WORLD_BVH, 0, false, false>), dim3(grid), dim3(64), lds_bytes, stream, p);
         break;
     default:
-        if (p.has_volumes) hipLaunchKernelGGL((k_render<WORLD_LINEAR_GENERIC, 0, true>), dim3(grid), dim3(64), lds_bytes, stream, p);
-        else hipLaunchKernelGGL((k_render<WORLD_LINEAR_GENERIC, 0, false>), dim3(grid), dim3(64), lds_bytes, stream, p);
+        if (p.has_volumes) hipLaunchKernelGGL((k_render<WORLD_LINEAR_GENERIC, 0, true, true>), dim3(grid), dim3(64), lds_bytes, stream, p);
+        else hipLaunchKernelGGL((k_render<WORLD_LINEAR_GENERIC, 0, false, true>), dim3(grid), dim3(64), lds_bytes, stream, p);
         break;
     }
     return hipGetLastError();
@@ -984,21 +999,24 @@ hipError_t render_kernel_attributes(const RenderParams &p, int *vgprs, int *stat
     hipFuncAttributes attr;
     const void *fn;
     if (p.world == WORLD_BVH)
-        fn = p.has_volumes ? reinterpret_cast<const void *>(k_render<WORLD_BVH, 0, true>) : reinterpret_cast<const void *>(k_render<WORLD_BVH, 0, false>);
+        fn = p.has_volumes ? (p.has_meshes ? reinterpret_cast<const void *>(k_render<WORLD_BVH, 0, true, true>)
+                                           : reinterpret_cast<const void *>(k_render<WORLD_BVH, 0, true, false>))
+                           : (p.has_meshes ? reinterpret_cast<const void *>(k_render<WORLD_BVH, 0, false, true>)
+                                           : reinterpret_cast<const void *>(k_render<WORLD_BVH, 0, false, false>));
     else if (p.world == WORLD_LINEAR_GENERIC)
-        fn = p.has_volumes ? reinterpret_cast<const void *>(k_render<WORLD_LINEAR_GENERIC, 0, true>)
-                           : reinterpret_cast<const void *>(k_render<WORLD_LINEAR_GENERIC, 0, false>);
+        fn = p.has_volumes ? reinterpret_cast<const void *>(k_render<WORLD_LINEAR_GENERIC, 0, true, true>)
+                           : reinterpret_cast<const void *>(k_render<WORLD_LINEAR_GENERIC, 0, false, true>);
     else {
         switch (p.sphere_regs) {
-        case 1: fn = reinterpret_cast<const void *>(k_render<WORLD_LINEAR_SPHERES, 1, false>); break;
-        case 2: fn = reinterpret_cast<const void *>(k_render<WORLD_LINEAR_SPHERES, 2, false>); break;
-        case 3: fn = reinterpret_cast<const void *>(k_render<WORLD_LINEAR_SPHERES, 3, false>); break;
-        case 4: fn = reinterpret_cast<const void *>(k_render<WORLD_LINEAR_SPHERES, 4, false>); break;
-        case 5: fn = reinterpret_cast<const void *>(k_render<WORLD_LINEAR_SPHERES, 5, false>); break;
-        case 6: fn = reinterpret_cast<const void *>(k_render<WORLD_LINEAR_SPHERES, 6, false>); break;
-        case 7: fn = reinterpret_cast<const void *>(k_render<WORLD_LINEAR_SPHERES, 7, false>); break;
-        case 8: fn = reinterpret_cast<const void *>(k_render<WORLD_LINEAR_SPHERES, 8, false>); break;
-        default: fn = reinterpret_cast<const void *>(k_render<WORLD_LINEAR_SPHERES, 0, false>); break;
+        case 1: fn = reinterpret_cast<const void *>(k_render<WORLD_LINEAR_SPHERES, 1, false, false>); break;
+        case 2: fn = reinterpret_cast<const void *>(k_render<WORLD_LINEAR_SPHERES, 2, false, false>); break;
+        case 3: fn = reinterpret_cast<const void *>(k_render<WORLD_LINEAR_SPHERES, 3, false, false>); break;
+        case 4: fn = reinterpret_cast<const void *>(k_render<WORLD_LINEAR_SPHERES, 4, false, false>); break;
+        case 5: fn = reinterpret_cast<const void *>(k_render<WORLD_LINEAR_SPHERES, 5, false, false>); break;
+        case 6: fn = reinterpret_cast<const void *>(k_render<WORLD_LINEAR_SPHERES, 6, false, false>); break;
+        case 7: fn = reinterpret_cast<const void *>(k_render<WORLD_LINEAR_SPHERES, 7, false, false>); break;
+        case 8: fn = reinterpret_cast<const void *>(k_render<WORLD_LINEAR_SPHERES, 8, false, false>); break;
+        default: fn = reinterpret_cast<const void *>(k_render<WORLD_LINEAR_SPHERES, 0, false, false>); break;
         }
     }
     hipError_t e = hipFuncGetAttributes(&attr, fn);
