@@ -133,9 +133,9 @@ int launch_frame(rtr_context *ctx, const rtr_camera *camera, const rtr_settings 
     p.clamp_indirect = st->clamp_indirect;
     p.seed_lo = (uint32_t)seed; p.seed_hi = (uint32_t)(seed >> 32);
     // render.rs:68-72: the tree when enable_bvh_tree, else the linear scan of scene.rs:141-157
-    if (st->enable_bvh_tree) { p.world = rtr::WORLD_BVH; p.stack_cap = fs.tree_height + 1u; }
+    if (st->enable_bvh_tree) { p.world = rtr::WORLD_BVH; p.stack_cap = fs.stack_depth + 1u; }
     else if (fs.spheres_only) { p.world = rtr::WORLD_LINEAR_SPHERES; p.stack_cap = 0u; }
-    else { p.world = rtr::WORLD_LINEAR_GENERIC; p.stack_cap = fs.mesh_height + 1u; }
+    else { p.world = rtr::WORLD_LINEAR_GENERIC; p.stack_cap = fs.mesh_stack_depth + 1u; }
     p.n_objects = fs.n_objects;
     p.has_volumes = fs.has_volumes ? 1u : 0u;
     p.has_meshes = fs.n_triangles > 0u ? 1u : 0u;

@@ -235,6 +235,7 @@ struct Flattener {
     std::vector<uint32_t> &obj_height; // per object: Split nodes on its longest root-to-leaf path
     const std::vector<uint32_t> &obj_leaf_base; // per object: first leaf slot = its rank block in the REFERENCE depth-first order
     bool leaf_pairs = true;
+    std::vector<uint32_t> obj_pushes; // per object: node records on its longest root-to-leaf path
 
     // Box of a flattened ref's own Split node, needed by its parent.
     struct Emitted {
@@ -242,6 +243,7 @@ struct Flattener {
         Box box;
         uint32_t height;
         bool has_volume = false; // the subtree holds a Volume leaf
+        uint32_t pushes = 0;     // node records on the longest path: what the walk can push (a leaf pair has no record)
     };
 
     // Volume (lib/volume.rs:19-32) over a sphere boundary: hot = boundary centre, radius, radius^2, -1/density
@@ -297,7 +299,7 @@ struct Flattener {
         Emitted l = emit_mesh_node(object, mb, t, n.left, leaf_base);
         Emitted r = emit_mesh_node(object, mb, t, n.right, leaf_base);
         fill_node(idx, l, r);
-        return {idx, n.box, 1 + std::max(l.height, r.height)};
+        return {idx, n.box, 1 + std::max(l.height, r.height), false, 1 + std::max(l.pushes, r.pushes)};
     }
 
     Emitted emit_object(uint32_t object) {
@@ -316,6 +318,8 @@ struct Flattener {
         obj_ref[object] = e.ref;
         obj_box[object] = e.box;
         obj_height[object] = e.height;
+        if (obj_pushes.size() < desc.n_objects) obj_pushes.resize(desc.n_objects, 0u);
+        obj_pushes[object] = e.pushes;
         return e;
     }
 
@@ -340,7 +344,7 @@ struct Flattener {
         Emitted l = emit_scene_node(n.left);
         Emitted r = emit_scene_node(n.right);
         fill_node(idx, l, r);
-        return {idx, n.box, 1 + std::max(l.height, r.height), l.has_volume || r.has_volume};
+        return {idx, n.box, 1 + std::max(l.height, r.height), l.has_volume || r.has_volume, 1 + std::max(l.pushes, r.pushes)};
     }
 
     void fill_node(uint32_t idx, const Emitted &l, const Emitted &r) {
@@ -553,6 +557,7 @@ int build_flat_scene(const rtr_scene_desc &desc, FlatScene &out, std::string &er
     out.root_ref = root.ref;
     for (int k = 0; k < 3; k++) { out.root_box[k] = root.box.mn[k]; out.root_box[3 + k] = root.box.mx[k]; }
     out.tree_height = root.height;
+    out.stack_depth = root.pushes;
     if (out.leaf_hot.size() > REF_INDEX || out.nodes.size() > REF_INDEX) { err = "scene too large"; return RTR_ERR_INVALID_ARGUMENT; }
 
     // ---- the linear world's views (scene.rs:141-157): objects in Scene.objects order ----
@@ -564,6 +569,7 @@ int build_flat_scene(const rtr_scene_desc &desc, FlatScene &out, std::string &er
         d.ref = obj_ref[i];
         for (int k = 0; k < 3; k++) { d.box[k] = obj_box[i].mn[k]; d.box[3 + k] = obj_box[i].mx[k]; }
         out.mesh_height = std::max(out.mesh_height, obj_height[i]);
+        if (i < fl.obj_pushes.size()) out.mesh_stack_depth = std::max(out.mesh_stack_depth, fl.obj_pushes[i]);
         if (desc.objects[i].kind == RTR_OBJ_MESH) out.n_triangles += desc.meshes[desc.objects[i].index].n_tris;
     }
     if (out.spheres_only) {

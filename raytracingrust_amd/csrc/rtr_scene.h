@@ -28,6 +28,9 @@ struct FlatScene {
     float root_box[6] = {0, 0, 0, 0, 0, 0};
     uint32_t split_nodes = 0;   // Split nodes of the flattened trees, collapsed leaf pairs included
     uint32_t tree_height = 0;   // Split nodes on the longest root-to-leaf path of the scene tree
+    uint32_t stack_depth = 0;   // node records on the longest path of the flattened tree: the most the walk can push
+                                // (<= tree_height: a collapsed leaf pair has no record)
+    uint32_t mesh_stack_depth = 0; // same, over the mesh subtrees alone
     uint32_t mesh_height = 0;   // same, over the mesh subtrees alone (linear world with meshes)
     bool spheres_only = true;
     bool has_volumes = false;   // a Volume leaf exists: traversal must keep the reference's visit set and order

@@ -13,6 +13,12 @@ using namespace rtr;
 static int fails = 0;
 #define CHECK(c) do { if (!(c)) { std::printf("CHECK failed: %s (line %d)\n", #c, __LINE__); fails++; } } while (0)
 
+// most entries the device walk can hold below `ref`: one push per node record on the path
+static uint32_t pushes(const FlatScene &fs, uint32_t ref) {
+    if (ref == REF_NONE || (ref & REF_LEAF) || ref >= fs.nodes.size()) return 0;
+    return 1 + std::max(pushes(fs, fs.nodes[ref].lref), pushes(fs, fs.nodes[ref].rref));
+}
+
 static void walk(const FlatScene &fs, uint32_t ref, std::set<uint32_t> &leaves, uint32_t depth, uint32_t &height) {
     if (ref == REF_NONE) return;
     if (ref & REF_LEAF) {
@@ -49,7 +55,10 @@ static void check_scene(const Scene &scene, const char *name) {
         walk(fs, fs.root_ref, leaves, 0, height);
         CHECK(leaves.size() == fs.leaf_hot.size());          // every leaf reachable exactly once
         CHECK(fs.leaf_hot.size() == fs.leaf_cold.size());
-        CHECK(height == fs.tree_height);                      // the traversal-stack bound is the real height
+        CHECK(height == fs.tree_height);                      // Split nodes on the longest path, collapsed pairs included
+        CHECK(pushes(fs, fs.root_ref) == fs.stack_depth);     // the device stack (stack_depth + 1 entries, unchecked) is large enough
+        for (const DevObject &ob : fs.objects) CHECK(pushes(fs, ob.ref) <= fs.mesh_stack_depth || !(d.objects[&ob - fs.objects.data()].kind == RTR_OBJ_MESH));
+        CHECK(fs.stack_depth <= fs.tree_height && fs.mesh_stack_depth <= fs.mesh_height);
         CHECK(fs.split_nodes == 0 || fs.split_nodes + 1 >= fs.leaf_hot.size());
         CHECK(o.leaf_pairs ? fs.nodes.size() <= fs.split_nodes : fs.nodes.size() == fs.split_nodes);
         for (const DevLeafCold &c : fs.leaf_cold) CHECK(c.material < fs.materials.size() && c.object < fs.n_objects);
