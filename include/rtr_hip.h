@@ -250,6 +250,12 @@ int rtr_kernel_times_ms(rtr_context *ctx, float *out, uint32_t cap);
 /* Device self-test: the kernels' correctly-rounded square root (csrc/rtr_kernels.hip rt_sqrt) against the
  * compiler's sqrtf() over all 2^32 f32 bit patterns; *mismatches must come back 0. */
 int rtr_selftest_sqrt(rtr_context *ctx, uint64_t *mismatches);
+/* Device self-test: the kernels' shared-denominator division (csrc/rtr_kernels.hip shared_div: camera u,v and sphere
+ * normals) against the compiler's correctly rounded n / denominator, for every f32 bit pattern n in
+ * [numerator_lo_bits, numerator_hi_bits]; *mismatches must come back 0 for 2^-20 <= |denominator| <= 2^40 and
+ * numerators that are +0 or have 2^-40 <= |n| <= 2^60 (a denominator outside its range counts as one mismatch). */
+int rtr_selftest_div(rtr_context *ctx, float denominator, uint32_t numerator_lo_bits, uint32_t numerator_hi_bits,
+                     uint64_t *mismatches);
 /* Device-counted ray segments of the same launches, in the same order. */
 int rtr_segment_counts(rtr_context *ctx, uint64_t *out, uint32_t cap);
 

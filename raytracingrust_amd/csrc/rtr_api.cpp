@@ -22,6 +22,7 @@ hipError_t launch_resolve(const float *sum_rgba, uint32_t spp, uint32_t n_pixels
                           hipStream_t stream);
 hipError_t render_kernel_attributes(const RenderParams &p, int *vgprs, int *static_lds);
 hipError_t launch_selftest_sqrt(unsigned long long *d_mismatches, hipStream_t stream);
+hipError_t launch_selftest_div(float d, uint32_t lo_bits, uint32_t hi_bits, unsigned long long *d_mismatches, hipStream_t stream);
 } // namespace rtr
 
 #ifndef RTR_BVH_LDS_MATERIALS
@@ -472,6 +473,20 @@ int rtr_selftest_sqrt(rtr_context *ctx, uint64_t *mismatches) {
     RTR_HIP_TRY(ctx, hipSetDevice(ctx->device));
     RTR_HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, sizeof(unsigned long long), ctx->stream));
     RTR_HIP_TRY(ctx, rtr::launch_selftest_sqrt(ctx->d_counters, ctx->stream));
+    unsigned long long bad = 0;
+    RTR_HIP_TRY(ctx, hipMemcpyAsync(&bad, ctx->d_counters, sizeof bad, hipMemcpyDeviceToHost, ctx->stream));
+    RTR_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    *mismatches = bad;
+    return RTR_OK;
+}
+
+int rtr_selftest_div(rtr_context *ctx, float denominator, uint32_t numerator_lo_bits, uint32_t numerator_hi_bits, uint64_t *mismatches) {
+    if (!ctx || !mismatches) return RTR_ERR_INVALID_ARGUMENT;
+    if (ctx->device < 0) return fail(ctx, RTR_ERR_NO_DEVICE, "host-only context: no HIP device bound (there is no CPU fallback)");
+    if (numerator_lo_bits > numerator_hi_bits) return fail(ctx, RTR_ERR_INVALID_ARGUMENT, "empty numerator range");
+    RTR_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    RTR_HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, sizeof(unsigned long long), ctx->stream));
+    RTR_HIP_TRY(ctx, rtr::launch_selftest_div(denominator, numerator_lo_bits, numerator_hi_bits, ctx->d_counters, ctx->stream));
     unsigned long long bad = 0;
     RTR_HIP_TRY(ctx, hipMemcpyAsync(&bad, ctx->d_counters, sizeof bad, hipMemcpyDeviceToHost, ctx->stream));
     RTR_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));

@@ -69,7 +69,7 @@ static_assert(sizeof(DevObject) == 32, "object record");
 
 struct alignas(16) DevMaterial {
     float rgb[3]; float param;
-    uint32_t kind, first, second, pad;
+    uint32_t kind, first, second, pad; // Mix: first / second = child handles.  Dielectric: f32 bits of 1/ir, r0^2 (front), r0^2 (back)
 };
 static_assert(sizeof(DevMaterial) == 32, "material record");
 

@@ -154,6 +154,39 @@ RTR_DEV uint32_t sat_u8(float f) {
     return (uint32_t)f;
 }
 
+// Division by a denominator that many numerators share.  hipcc's correctly rounded n / d is
+//     d' = div_scale(d); r0 = rcp(d'); e0 = fma(-d', r0, 1); r1 = fma(e0, r0, r0);            -- depends on d only
+//     n' = div_scale(n); q0 = n' * r1; e1 = fma(-d', q0, n'); q1 = fma(e1, r1, q0); e2 = fma(-d', q1, n');
+//     q = div_fmas(e2, r1, q1); div_fixup(q, d, n)
+// where div_scale / div_fmas only rescale operands with extreme exponents and div_fixup only patches zero, infinite
+// and NaN operands.  For 2^-20 <= |d| <= 2^40 and n == +0 or 2^-40 <= |n| <= 2^60 none of them changes a bit, so the
+// quotient is the five FMA-class operations below on a reciprocal computed once: the same operations in the same
+// order, hence the same correctly rounded result (rtr_selftest_div sweeps numerator ranges against `/` on the device).
+struct SharedDiv {
+    float d, r1;
+    bool ok; // the denominator is in the range above
+};
+RTR_DEV SharedDiv shared_div_prepare(float d) {
+    SharedDiv s;
+    s.d = d;
+    const float r0 = __builtin_amdgcn_rcpf(d);
+    const float e0 = __builtin_fmaf(-d, r0, 1.0f);
+    s.r1 = __builtin_fmaf(e0, r0, r0);
+    s.ok = fabsf(d) >= 0x1p-20f && fabsf(d) <= 0x1p40f;
+    return s;
+}
+RTR_DEV float shared_div(float n, float d, float r1) {
+    const float q0 = n * r1;
+    const float e1 = __builtin_fmaf(-d, q0, n);
+    const float q1 = __builtin_fmaf(e1, r1, q0);
+    const float e2 = __builtin_fmaf(-d, q1, n);
+    return __builtin_fmaf(e2, r1, q1);
+}
+RTR_DEV bool shared_div_numerators_ok(V3 n) { // every component in [2^-40, 2^60] (a zero takes the slow path: rare)
+    const float lo = fminf(fminf(fabsf(n.x), fabsf(n.y)), fabsf(n.z)), hi = fmaxf(fmaxf(fabsf(n.x), fabsf(n.y)), fabsf(n.z));
+    return lo >= 0x1p-40f && hi <= 0x1p60f;
+}
+
 // --- intersection ------------------------------------------------------------------------------------
 struct Ray { V3 o, d; };
 
@@ -556,7 +589,16 @@ RTR_DEV bool world_hit(const RenderParams &p, const Ray &r, Hit &h, uint32_t *st
         const float4 w = *reinterpret_cast<const float4 *>(lds_spheres + best * 8); // centre, radius
         h.material = lds_spheres[best * 8 + 5];
         h.point = add(r.o, scale(r.d, closest));
-        V3 outward = divs(sub(h.point, mk(w.x, w.y, w.z)), w.w);
+        const V3 pc = sub(h.point, mk(w.x, w.y, w.z));
+        V3 outward;
+#ifndef RTR_X_NO_SHARED_DIV
+        // (p - c) / r, objects.rs:46: three quotients over one radius, whose reciprocal was prepared at staging
+        const float r1 = __uint_as_float(lds_spheres[best * 8 + 6]);
+        if (lds_spheres[best * 8 + 7] != 0u && shared_div_numerators_ok(pc))
+            outward = mk(shared_div(pc.x, w.w, r1), shared_div(pc.y, w.w, r1), shared_div(pc.z, w.w, r1));
+        else
+#endif
+            outward = divs(pc, w.w);
         face_forward(h, r, outward);
         return true;
     } else if constexpr (WORLD == WORLD_LINEAR_SPHERES) {
@@ -651,6 +693,13 @@ RTR_DEV float reflectance(float cosine, float idx) { // materials.rs:103-108; po
     return r0 + (1.0f - r0) * (x * x4);
 }
 
+RTR_DEV float reflectance_r0(float cosine, float r0) { // the same with r0 = ((1 - idx) / (1 + idx))^2 given
+    float x = 1.0f - cosine;
+    float x2 = x * x;
+    float x4 = x2 * x2;
+    return r0 + (1.0f - r0) * (x * x4);
+}
+
 // Material records: from the LDS copy when the kernel staged one (lds_mats != nullptr), else from HBM/L1.
 RTR_DEV void material_load(const RenderParams &p, const uint32_t *lds_mats, uint32_t id, float4 &q0, float4 &q1) {
     if (lds_mats) {
@@ -718,6 +767,13 @@ __global__ __launch_bounds__(64, RTR_X_WAVES_PER_EU) void k_render(const RenderP
             sr.cx[i] = sp.center[0]; sr.cy[i] = sp.center[1]; sr.cz[i] = sp.center[2]; sr.r2[i] = sp.radius2;
         }
         for (uint32_t i = lane; i < NS * 8u; i += 64u) lds_spheres[i] = reinterpret_cast<const uint32_t *>(p.lin_spheres)[i];
+        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_wave_barrier();
+        if (lane < NS) { // the two pad words of the LDS copy: the radius' prepared reciprocal and its validity
+            const SharedDiv sd = shared_div_prepare(__uint_as_float(lds_spheres[lane * 8u + 3u]));
+            lds_spheres[lane * 8u + 6u] = __float_as_uint(sd.r1);
+            lds_spheres[lane * 8u + 7u] = sd.ok ? 1u : 0u;
+        }
     }
     if (p.lds_materials)
         for (uint32_t i = lane; i < p.lds_materials * 8u; i += 64u) lds_mat_base[i] = reinterpret_cast<const uint32_t *>(p.materials)[i];
@@ -747,11 +803,27 @@ __global__ __launch_bounds__(64, RTR_X_WAVES_PER_EU) void k_render(const RenderP
     Ray ray;
     ray.o = cam_o; ray.d = cam_o;
 
+#ifndef RTR_X_NO_SHARED_DIV
+    // (x + xi) / (W - 1), (y + xi') / (H - 1): wave-uniform denominators in [1, 2^31] (else the plain division),
+    // numerators 0 or >= 2^-23 -- inside shared_div's range
+    const SharedDiv div_w = shared_div_prepare(p.width_m1), div_h = shared_div_prepare(p.height_m1);
+    const bool uv_fast = div_w.ok && div_h.ok;
+#endif
     auto start_sample = [&](uint32_t si) {
         rng.state = hash32(hp + si * 0x9E3779B9u);
         // render.rs:88-89
-        float u = (fx + rng_unit_inclusive(rng)) / p.width_m1;
-        float v = (fy + rng_unit_inclusive(rng)) / p.height_m1;
+        float u = fx + rng_unit_inclusive(rng);
+        float v = fy + rng_unit_inclusive(rng);
+#ifndef RTR_X_NO_SHARED_DIV
+        if (uv_fast) {
+            u = shared_div(u, div_w.d, div_w.r1);
+            v = shared_div(v, div_h.d, div_h.r1);
+        } else
+#endif
+        {
+            u = u / p.width_m1;
+            v = v / p.height_m1;
+        }
         // camera.rs:19-24
         ray.o = cam_o;
         ray.d = sub(sub(add(cam_llc, scale(cam_h, u)), scale(cam_v, v)), cam_o);
@@ -833,13 +905,26 @@ __global__ __launch_bounds__(64, RTR_X_WAVES_PER_EU) void k_render(const RenderP
             } else if (kind == 2u) { // Emission, materials.rs:86-91
                 scattered = false; term = rgb;
             } else if (kind == 3u) { // Dielectric, materials.rs:111-138
+#ifndef RTR_X_NO_DIELECTRIC_CONSTANTS
+                // 1/ir and the two Schlick r0^2 values are constants of the material, divided once on the host
+                // (rtr_scene.cpp) into the record's spare words: re-read here rather than kept live across the sampler
+                float4 dq0, dq1;
+                material_load(p, lds_mats, mid, dq0, dq1);
+                const float ratio = h.front_face ? dq1.y : param;
+                const float r0sq = h.front_face ? dq1.z : dq1.w;
+#else
                 float ratio = h.front_face ? 1.0f / param : param;
+#endif
                 V3 unit = normalize(ray.d);
                 float cos_theta = fminf(dot(h.normal, neg(unit)), 1.0f);
                 float sin_theta = rt_sqrt(1.0f - cos_theta * cos_theta);
                 bool cannot_refract = (ratio * sin_theta) > 1.0f;
                 bool refl = cannot_refract;
+#ifndef RTR_X_NO_DIELECTRIC_CONSTANTS
+                if (!refl) refl = reflectance_r0(cos_theta, r0sq) > rng_unit(rng); // no draw on TIR (short-circuit ||)
+#else
                 if (!refl) refl = reflectance(cos_theta, ratio) > rng_unit(rng); // no draw on TIR (short-circuit ||)
+#endif
                 ndir = refl ? reflect(unit, h.normal) : refract(unit, h.normal, ratio);
                 mid = 0xFFFFFFFEu; // attenuation (1,1,1): x*1 == x exactly, nothing to replay
             } else { // Isotropic, volume.rs:80-88: the un-normalised ball sample is the direction
@@ -946,6 +1031,24 @@ __global__ __launch_bounds__(256) void k_selftest_sqrt(unsigned long long *misma
         bad += same ? 0u : 1u;
     }
     if (bad) atomicAdd(mismatches, (unsigned long long)bad);
+}
+
+// Device self-test: shared_div(n, d) against n / d for every f32 bit pattern n in [lo_bits, hi_bits].
+__global__ __launch_bounds__(256) void k_selftest_div(float d, uint32_t lo_bits, uint32_t hi_bits, unsigned long long *mismatches) {
+    const SharedDiv sd = shared_div_prepare(d);
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    uint32_t bad = sd.ok ? 0u : 1u;
+    for (uint64_t b = (uint64_t)lo_bits + blockIdx.x * blockDim.x + threadIdx.x; b <= hi_bits; b += stride) {
+        const float n = __uint_as_float((uint32_t)b);
+        const float q = shared_div(n, sd.d, sd.r1), ref = n / d;
+        bad += (__float_as_uint(q) == __float_as_uint(ref)) ? 0u : 1u;
+    }
+    if (bad) atomicAdd(mismatches, (unsigned long long)bad);
+}
+
+hipError_t launch_selftest_div(float d, uint32_t lo_bits, uint32_t hi_bits, unsigned long long *d_mismatches, hipStream_t stream) {
+    hipLaunchKernelGGL(k_selftest_div, dim3(8192), dim3(256), 0, stream, d, lo_bits, hi_bits, d_mismatches);
+    return hipGetLastError();
 }
 
 hipError_t launch_selftest_sqrt(unsigned long long *d_mismatches, hipStream_t stream) {

@@ -382,6 +382,22 @@ int build_flat_scene(const rtr_scene_desc &desc, FlatScene &out, std::string &er
             if (m.first >= desc.n_materials || m.second >= desc.n_materials) { err = "mix child out of bounds"; return RTR_ERR_BAD_INDEX; }
             if (m.first <= i || m.second <= i) { err = "mix children must follow their parent in the materials array"; return RTR_ERR_INVALID_ARGUMENT; }
         }
+        if (m.kind == RTR_MAT_DIELECTRIC) {
+            // Dielectric::scatter divides twice per hit by constants of the material (materials.rs:113-118 `1.0 / ir`,
+            // materials.rs:104-105 `((1 - ratio) / (1 + ratio))^2` for ratio = 1/ir or ir).  The quotients are computed
+            // here once, with the same f32 operations (IEEE division is correctly rounded on the host and on the
+            // device alike), into the record's otherwise unused words: first = 1/ir, second = r0^2 for the front face
+            // (ratio = 1/ir), pad = r0^2 for the back face (ratio = ir).
+            const float ir = m.param;
+            const float inv_ir = 1.0f / ir;
+            float r0_front = (1.0f - inv_ir) / (1.0f + inv_ir);
+            r0_front = r0_front * r0_front;
+            float r0_back = (1.0f - ir) / (1.0f + ir);
+            r0_back = r0_back * r0_back;
+            std::memcpy(&d.first, &inv_ir, 4);
+            std::memcpy(&d.second, &r0_front, 4);
+            std::memcpy(&d.pad, &r0_back, 4);
+        }
         out.materials[i] = d;
     }
     // ---- background (backgrounds.rs) ----

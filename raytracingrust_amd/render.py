@@ -166,6 +166,15 @@ class Renderer:
         self._check(self._lib.rtr_selftest_sqrt(self._ctx, C.byref(bad)))
         return int(bad.value)
 
+    def selftest_div(self, denominator: float, lo: float, hi: float) -> int:
+        """Mismatches between the kernels' shared-denominator division and n / denominator over every f32 n in
+        [lo, hi] (0 <= lo <= hi, or lo <= hi <= -0.0 handled by the caller's choice of bit range); must be 0."""
+        lo_bits = int(np.float32(lo).view(np.uint32))
+        hi_bits = int(np.float32(hi).view(np.uint32))
+        bad = C.c_uint64(0)
+        self._check(self._lib.rtr_selftest_div(self._ctx, C.c_float(denominator), lo_bits, hi_bits, C.byref(bad)))
+        return int(bad.value)
+
     def segment_counts(self, cap: int = 64) -> np.ndarray:
         out = np.zeros(cap, dtype=np.uint64)
         n = self._lib.rtr_segment_counts(self._ctx, out.ctypes.data_as(C.POINTER(C.c_uint64)), cap)
