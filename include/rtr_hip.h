@@ -24,7 +24,8 @@
  *     [the reference panics: scene.rs:75, mesh.rs:65, bvh.rs:99, render.rs:95];
  *   - the caller owns every buffer; inputs are copied during rtr_upload_scene and no host pointer is
  *     retained; host outputs are complete when the call returns [render() is synchronous, render.rs:61];
- *   - a context is single-threaded-use; distinct contexts are independent;
+ *   - calls on one context serialise on an internal mutex (one frame at a time, like the reference's blocking render());
+ *     distinct contexts are independent;
  *   - pixel layout is the reference's: row-major, y = 0 is the top row, RGBA8 with A = 255
  *     (render.rs:22-29,110);
  *   - random numbers: the reference uses an OS-seeded thread_rng() and is not reproducible; here every

@@ -8,6 +8,7 @@
 #include <chrono>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -29,6 +30,9 @@ hipError_t launch_selftest_div(float d, uint32_t lo_bits, uint32_t hi_bits, unsi
 #define RTR_BVH_LDS_MATERIALS 16u
 #endif
 
+// every entry point that takes a context holds its mutex for the duration of the call
+#define RTR_LOCK(ctx) std::lock_guard<std::recursive_mutex> rtr_guard_((ctx)->mu)
+
 namespace {
 constexpr int kRing = 64;
 thread_local std::string g_create_error;
@@ -39,6 +43,7 @@ struct rtr_context {
     hipStream_t stream = nullptr;
     std::string error;
     rtr::BuildOptions build_options;
+    mutable std::recursive_mutex mu; // a context is used by one thread at a time; concurrent calls serialise here
     // scene
     bool have_scene = false;
     rtr::FlatScene flat; // host copy (kept for introspection)
@@ -274,6 +279,7 @@ const char *rtr_last_error(const rtr_context *ctx) { return ctx ? ctx->error.c_s
 
 int rtr_upload_scene(rtr_context *ctx, const rtr_scene_desc *scene) {
     if (!ctx) return RTR_ERR_INVALID_ARGUMENT;
+    RTR_LOCK(ctx);
     if (!scene) return fail(ctx, RTR_ERR_INVALID_ARGUMENT, "null scene");
     auto t0 = std::chrono::steady_clock::now();
     rtr::FlatScene flat;
@@ -302,6 +308,7 @@ int rtr_upload_scene(rtr_context *ctx, const rtr_scene_desc *scene) {
 
 int rtr_set_option(rtr_context *ctx, const char *name, const char *value) {
     if (!ctx || !name || !value) return RTR_ERR_INVALID_ARGUMENT;
+    RTR_LOCK(ctx);
     const std::string n(name), v(value);
     if (n == "mesh_tree") { // takes effect at the next rtr_upload_scene
         if (v == "reference") ctx->build_options.sah_mesh_trees = false;
@@ -326,6 +333,7 @@ int rtr_set_option(rtr_context *ctx, const char *name, const char *value) {
 
 int rtr_scene_info_get(const rtr_context *ctx, rtr_scene_info *out) {
     if (!ctx || !out) return RTR_ERR_INVALID_ARGUMENT;
+    RTR_LOCK(ctx);
     if (!ctx->have_scene) return RTR_ERR_NO_SCENE;
     const rtr::FlatScene &fs = ctx->flat;
     std::memset(out, 0, sizeof *out);
@@ -339,6 +347,7 @@ int rtr_scene_info_get(const rtr_context *ctx, rtr_scene_info *out) {
 
 int64_t rtr_bvh_leaf_order(const rtr_context *ctx, uint64_t *out, uint64_t cap) {
     if (!ctx) return RTR_ERR_INVALID_ARGUMENT;
+    RTR_LOCK(ctx);
     if (!ctx->have_scene) return RTR_ERR_NO_SCENE;
     const auto &cold = ctx->flat.leaf_cold;
     if (out)
@@ -349,6 +358,7 @@ int64_t rtr_bvh_leaf_order(const rtr_context *ctx, uint64_t *out, uint64_t cap) 
 int rtr_render_frame_device(rtr_context *ctx, const rtr_camera *camera, const rtr_settings *settings, uint32_t width,
                             uint32_t height, uint64_t seed, uint8_t *d_rgba8, void *stream) {
     if (!ctx) return RTR_ERR_INVALID_ARGUMENT;
+    RTR_LOCK(ctx);
     if (!d_rgba8) return fail(ctx, RTR_ERR_INVALID_ARGUMENT, "null output");
     return launch_frame(ctx, camera, settings, width, height, seed, 0u, 1u, nullptr, d_rgba8, nullptr, (hipStream_t)stream);
 }
@@ -357,6 +367,7 @@ int rtr_render_tiles_device(rtr_context *ctx, const rtr_camera *camera, const rt
                             uint32_t height, uint64_t seed, uint32_t shard, uint32_t n_shards, float *d_sum_rgba,
                             void *stream) {
     if (!ctx) return RTR_ERR_INVALID_ARGUMENT;
+    RTR_LOCK(ctx);
     if (!d_sum_rgba) return fail(ctx, RTR_ERR_INVALID_ARGUMENT, "null output");
     return launch_frame(ctx, camera, settings, width, height, seed, shard, n_shards, d_sum_rgba, nullptr, nullptr, (hipStream_t)stream);
 }
@@ -365,6 +376,7 @@ int rtr_render_samples_device(rtr_context *ctx, const rtr_camera *camera, const 
                               uint32_t height, uint64_t seed, uint32_t sample_begin, uint32_t sample_count,
                               float *d_sum_rgba, void *stream) {
     if (!ctx) return RTR_ERR_INVALID_ARGUMENT;
+    RTR_LOCK(ctx);
     if (!d_sum_rgba) return fail(ctx, RTR_ERR_INVALID_ARGUMENT, "null output");
     return launch_frame(ctx, camera, settings, width, height, seed, 0u, 1u, d_sum_rgba, nullptr, nullptr, (hipStream_t)stream,
                         sample_begin, sample_count);
@@ -373,6 +385,7 @@ int rtr_render_samples_device(rtr_context *ctx, const rtr_camera *camera, const 
 int rtr_resolve_device(rtr_context *ctx, const float *d_sum_rgba, uint32_t samples_per_pixel, uint32_t width,
                        uint32_t height, uint8_t *d_rgba8, float *d_mean_rgb, void *stream) {
     if (!ctx) return RTR_ERR_INVALID_ARGUMENT;
+    RTR_LOCK(ctx);
     if (ctx->device < 0) return fail(ctx, RTR_ERR_NO_DEVICE, "host-only context: no HIP device bound (there is no CPU fallback)");
     if (!d_sum_rgba || width == 0 || height == 0) return fail(ctx, RTR_ERR_INVALID_ARGUMENT, "bad resolve arguments");
     RTR_HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -387,6 +400,7 @@ int rtr_resolve_device(rtr_context *ctx, const float *d_sum_rgba, uint32_t sampl
 int rtr_render(rtr_context *ctx, const rtr_camera *camera, const rtr_settings *settings, uint32_t width, uint32_t height,
                uint64_t seed, uint8_t *rgba8, float *mean_rgb) {
     if (!ctx) return RTR_ERR_INVALID_ARGUMENT;
+    RTR_LOCK(ctx);
     if (!rgba8 && !mean_rgb) return fail(ctx, RTR_ERR_INVALID_ARGUMENT, "no output requested");
     if (ctx->device < 0) return fail(ctx, RTR_ERR_NO_DEVICE, "host-only context: no HIP device bound (there is no CPU fallback)");
     int rc = check_settings(ctx, camera, settings, width, height);
@@ -427,6 +441,7 @@ int rtr_render_f32(rtr_context *ctx, const rtr_camera *camera, const rtr_setting
 
 int rtr_get_stats(rtr_context *ctx, rtr_stats *out) {
     if (!ctx || !out) return RTR_ERR_INVALID_ARGUMENT;
+    RTR_LOCK(ctx);
     std::memset(out, 0, sizeof *out);
     out->upload_ms = ctx->upload_ms;
     out->launches = ctx->launches;
@@ -453,6 +468,7 @@ int rtr_get_stats(rtr_context *ctx, rtr_stats *out) {
 
 int rtr_kernel_times_ms(rtr_context *ctx, float *out, uint32_t cap) {
     if (!ctx || !out) return RTR_ERR_INVALID_ARGUMENT;
+    RTR_LOCK(ctx);
     if (ctx->device < 0 || ctx->launches == 0) return 0;
     RTR_HIP_TRY(ctx, hipSetDevice(ctx->device));
     RTR_HIP_TRY(ctx, hipDeviceSynchronize());
@@ -469,6 +485,7 @@ int rtr_kernel_times_ms(rtr_context *ctx, float *out, uint32_t cap) {
 
 int rtr_selftest_sqrt(rtr_context *ctx, uint64_t *mismatches) {
     if (!ctx || !mismatches) return RTR_ERR_INVALID_ARGUMENT;
+    RTR_LOCK(ctx);
     if (ctx->device < 0) return fail(ctx, RTR_ERR_NO_DEVICE, "host-only context: no HIP device bound (there is no CPU fallback)");
     RTR_HIP_TRY(ctx, hipSetDevice(ctx->device));
     RTR_HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, sizeof(unsigned long long), ctx->stream));
@@ -482,6 +499,7 @@ int rtr_selftest_sqrt(rtr_context *ctx, uint64_t *mismatches) {
 
 int rtr_selftest_div(rtr_context *ctx, float denominator, uint32_t numerator_lo_bits, uint32_t numerator_hi_bits, uint64_t *mismatches) {
     if (!ctx || !mismatches) return RTR_ERR_INVALID_ARGUMENT;
+    RTR_LOCK(ctx);
     if (ctx->device < 0) return fail(ctx, RTR_ERR_NO_DEVICE, "host-only context: no HIP device bound (there is no CPU fallback)");
     if (numerator_lo_bits > numerator_hi_bits) return fail(ctx, RTR_ERR_INVALID_ARGUMENT, "empty numerator range");
     RTR_HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -496,6 +514,7 @@ int rtr_selftest_div(rtr_context *ctx, float denominator, uint32_t numerator_lo_
 
 int rtr_segment_counts(rtr_context *ctx, uint64_t *out, uint32_t cap) {
     if (!ctx || !out) return RTR_ERR_INVALID_ARGUMENT;
+    RTR_LOCK(ctx);
     if (ctx->device < 0 || ctx->launches == 0) return 0;
     RTR_HIP_TRY(ctx, hipSetDevice(ctx->device));
     RTR_HIP_TRY(ctx, hipDeviceSynchronize());

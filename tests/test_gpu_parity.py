@@ -470,3 +470,34 @@ def test_sah_scene_tree_renders_the_same_frame():
         r.set_option("scene_tree", "sah")
         c, st, o_st = run_both(r, fog, 64, 48, 9)
     assert c["mismatched_pixels"] == 0 and st.segments == o_st.segments
+
+
+def test_concurrent_calls_on_one_context_serialise():
+    """include/rtr_hip.h: calls on one context take its internal mutex.  Four threads render different seeds through
+    the same Renderer at once (ctypes drops the GIL inside the call); every frame must equal its single-threaded
+    twin."""
+    import threading
+
+    scene = benchmark_scene(2)
+    w, h = 96, 64
+    with rt.Renderer(0) as r:
+        r.upload_scene(scene)
+        want = {seed: r.render(w, h, seed=seed, want_rgba8=True, want_mean=True) for seed in range(4)}
+        got, errors = {}, []
+
+        def work(seed):
+            try:
+                for _ in range(3):
+                    got[seed] = r.render(w, h, seed=seed, want_rgba8=True, want_mean=True)
+            except Exception as e:  # noqa: BLE001
+                errors.append(e)
+
+        threads = [threading.Thread(target=work, args=(seed,)) for seed in range(4)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+    assert not errors, errors
+    for seed in range(4):
+        assert np.array_equal(got[seed][0], want[seed][0])
+        assert np.array_equal(got[seed][1].view(np.uint32), want[seed][1].view(np.uint32))
