@@ -262,6 +262,26 @@ class SkyMap : public Background { // backgrounds.rs:51-56: row-major texels, ro
     SkyMap(std::vector<float> rgb, uint32_t width, uint32_t height) : image(std::move(rgb)), width(width), height(height) {
         if (image.size() != (size_t)width * height * 3 || image.empty()) throw std::runtime_error("SkyMap: image must hold width*height RGB triples");
     }
+    // Colour Portable Float Map: "PF\n<w> <h>\n<scale>\n", rows bottom first, scale < 0 = little-endian samples.
+    static std::unique_ptr<SkyMap> from_pfm(const std::string &path) {
+        std::ifstream in(path, std::ios::binary);
+        if (!in) throw std::runtime_error("cannot open " + path);
+        std::string magic; long w = 0, h = 0; double scale = 0;
+        in >> magic >> w >> h >> scale;
+        if (!in || magic != "PF" || w <= 0 || h <= 0 || scale == 0.0) throw std::runtime_error(path + ": not a colour PFM file");
+        in.get(); // the single whitespace byte that ends the header
+        std::vector<float> rgb((size_t)w * h * 3);
+        const size_t row = (size_t)w * 3;
+        for (long y = h - 1; y >= 0; y--) { // file rows run bottom to top; row 0 of a SkyMap is the top scanline
+            in.read(reinterpret_cast<char *>(rgb.data() + (size_t)y * row), (std::streamsize)(row * 4));
+            if (!in) throw std::runtime_error(path + ": truncated PFM pixel data");
+        }
+        const uint16_t probe = 1;
+        const bool host_little = *reinterpret_cast<const uint8_t *>(&probe) == 1;
+        if ((scale < 0) != host_little)
+            for (float &f : rgb) { uint32_t u; std::memcpy(&u, &f, 4); u = __builtin_bswap32(u); std::memcpy(&f, &u, 4); }
+        return std::make_unique<SkyMap>(std::move(rgb), (uint32_t)w, (uint32_t)h);
+    }
     std::vector<float> image; uint32_t width, height;
     void lower(rtr_background &o) const override { o = rtr_background{}; o.kind = RTR_BG_SKYMAP; o.image = image.data(); o.width = width; o.height = height; }
 };

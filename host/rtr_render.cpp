@@ -5,7 +5,8 @@
 //   rtr_render --scene ... --host-only --info                            (no GPU: lowering + BVH statistics only)
 //
 // Options: --bvh 0|1, --depth N, --mode Full|Clay|Random|Normal, --f32 file (raw mean radiance floats), --device N,
-//          --fast-trees (rebuild mesh and scene trees with the surface-area heuristic: same hits, faster walk).
+//          --fast-trees (rebuild mesh and scene trees with the surface-area heuristic: same hits, faster walk),
+//          --sky file.pfm (replace the scene's background by a SkyMap read from a colour Portable Float Map).
 #include <chrono>
 #include <cstdio>
 #include <cstring>
@@ -38,7 +39,7 @@ static rtr::Scene gui_scene(const std::string &mesh_dir) { // src/gui.rs:56-119 
 }
 
 int main(int argc, char **argv) {
-    std::string scene_path, preset, mesh_dir = "data/meshes", out, f32_out, mode;
+    std::string scene_path, preset, mesh_dir = "data/meshes", out, f32_out, mode, sky;
     size_t width = 256, height = 256;
     long spp = -1, depth = -1, bvh = -1;
     uint64_t seed = 0x5EED;
@@ -63,12 +64,14 @@ int main(int argc, char **argv) {
         else if (a == "--info") info = true;
         else if (a == "--host-only") host_only = true;
         else if (a == "--fast-trees") fast_trees = true;
+        else if (a == "--sky") sky = next();
         else { std::fprintf(stderr, "unknown option %s\n", a.c_str()); return 2; }
     }
     try {
         rtr::Scene scene = !scene_path.empty() ? rtr::Scene::from_file(scene_path)
                            : preset == "gui"   ? gui_scene(mesh_dir)
                                                : throw std::runtime_error("give --scene FILE or --preset gui");
+        if (!sky.empty()) scene.background = rtr::SkyMap::from_pfm(sky); // SkyMap::new (backgrounds.rs:58-81) from a .pfm
         if (spp >= 0) scene.settings.samples_per_pixel = (uint32_t)spp;
         if (depth >= 0) scene.settings.max_ray_depth = (uint8_t)depth;
         if (bvh >= 0) scene.settings.enable_bvh_tree = bvh != 0;

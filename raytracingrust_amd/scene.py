@@ -272,6 +272,45 @@ class GradientBackground:
         self.top, self.bottom = _v3(self.top), _v3(self.bottom)
 
 
+def read_pfm(path: str) -> np.ndarray:
+    """Colour Portable Float Map ("PF"): header `PF\n<width> <height>\n<scale>\n`, then rows of RGB f32 stored bottom
+    row first; a negative scale means little-endian samples.  Returns [height, width, 3] float32 with row 0 = top."""
+    with open(path, "rb") as fh:
+        data = fh.read()
+    pos = 0
+    tokens = []
+    while len(tokens) < 4:  # whitespace-separated header tokens; exactly one whitespace byte ends the header
+        while data[pos:pos + 1].isspace():
+            pos += 1
+        end = pos
+        while end < len(data) and not data[end:end + 1].isspace():
+            end += 1
+        if end == pos:
+            raise ValueError("truncated PFM header")
+        tokens.append(data[pos:end])
+        pos = end
+    pos += 1
+    if tokens[0] != b"PF":
+        raise ValueError("not a colour PFM file (magic must be 'PF'; greyscale 'Pf' is not a sky map)")
+    width, height, scale = int(tokens[1]), int(tokens[2]), float(tokens[3])
+    if width <= 0 or height <= 0 or scale == 0.0:
+        raise ValueError("bad PFM header")
+    need = width * height * 3 * 4
+    if len(data) - pos < need:
+        raise ValueError("truncated PFM pixel data")
+    dt = np.dtype("<f4") if scale < 0 else np.dtype(">f4")
+    img = np.frombuffer(data, dtype=dt, count=width * height * 3, offset=pos).reshape(height, width, 3)
+    return np.ascontiguousarray(img[::-1].astype(np.float32))
+
+
+def write_pfm(path: str, image) -> None:
+    """Little-endian colour PFM of a [height, width, 3] array whose row 0 is the top scanline (tests, tools)."""
+    img = np.asarray(image, dtype="<f4")
+    with open(path, "wb") as fh:
+        fh.write(b"PF\n%d %d\n-1.0\n" % (img.shape[1], img.shape[0]))
+        fh.write(np.ascontiguousarray(img[::-1]).tobytes())
+
+
 class SkyMap:
     """backgrounds.rs:51-92: `image` is height x width x 3 float32, row 0 = top scanline.  The reference
     fills it from an EXR (SkyMap::new); EXR decoding is outside the hot path, so this takes the texels."""
@@ -285,9 +324,12 @@ class SkyMap:
     @classmethod
     def new(cls, path: str) -> "SkyMap":
         """SkyMap::new (backgrounds.rs:58-81): texels from an OpenEXR file (raytracingrust_amd/exr.py: scanline files,
-        none / RLE / ZIPS / ZIP compression) or from a float32 `.npy` array of shape [height, width, 3]."""
+        none / RLE / ZIPS / ZIP compression), a colour Portable Float Map (`.pfm`) or a float32 `.npy` array of shape
+        [height, width, 3]."""
         if path.lower().endswith(".npy"):
             return cls(np.load(path, allow_pickle=False))
+        if path.lower().endswith(".pfm"):
+            return cls(read_pfm(path))
         from .exr import read_exr
 
         return cls(read_exr(path))

@@ -92,6 +92,16 @@ int main(int argc, char **argv) {
         s.add_object(std::make_unique<Sphere>(Vec3{0, 0, -1}, 0.5f, lam));
         check_scene(s, "single");
     }
+    if (argc > 2) { // a little-endian colour PFM written by the Python side: 3 x 2 texels, texel (x, y) = 10*y + x + 0.25*c
+        auto sky = SkyMap::from_pfm(argv[2]);
+        CHECK(sky->width == 3 && sky->height == 2);
+        for (uint32_t y = 0; y < 2; y++)
+            for (uint32_t x = 0; x < 3; x++)
+                for (uint32_t c = 0; c < 3; c++) CHECK(sky->image[(y * 3 + x) * 3 + c] == 10.0f * y + x + 0.25f * c);
+        Scene s;
+        s.background = std::move(sky);
+        check_scene(s, "pfm sky");
+    }
     std::printf("%s\n", fails ? "FAILED" : "ok");
     return fails != 0;
 }

@@ -61,3 +61,28 @@ def test_npy_sky_and_errors(tmp_path):
     (tmp_path / "piz.exr").write_bytes(bytes(data))
     with pytest.raises(exr.ExrError):
         exr.read_exr(str(tmp_path / "piz.exr"))
+
+
+def test_pfm_sky_maps_round_trip_in_both_byte_orders(tmp_path):
+    """SURVEY 8f N2: `.pfm` ingest for SkyMap::new.  Rows are stored bottom first; a negative scale marks
+    little-endian samples."""
+    from raytracingrust_amd.scene import read_pfm, write_pfm
+
+    rng = np.random.default_rng(11)
+    img = rng.uniform(0.0, 30.0, (13, 29, 3)).astype(np.float32)
+    le = str(tmp_path / "sky_le.pfm")
+    write_pfm(le, img)
+    assert np.array_equal(read_pfm(le), img)
+    sky = rt.SkyMap.new(le)
+    assert sky.width == 29 and sky.height == 13 and np.array_equal(sky.image, img)
+    be = str(tmp_path / "sky_be.pfm")
+    with open(be, "wb") as fh:  # big-endian variant, positive scale, Windows-style header whitespace
+        fh.write(b"PF\r\n29 13\r\n1.0\n")
+        fh.write(np.ascontiguousarray(img[::-1]).astype(">f4").tobytes())
+    assert np.array_equal(read_pfm(be), img)
+    for bad in (b"Pf\n2 2\n-1\n" + b"\0" * 16, b"PF\n2 2\n-1\n" + b"\0" * 47, b"PF\n0 2\n-1\n", b"PF\n2"):
+        p = str(tmp_path / "bad.pfm")
+        with open(p, "wb") as fh:
+            fh.write(bad)
+        with pytest.raises(ValueError):
+            read_pfm(p)

@@ -22,6 +22,13 @@ def test_scene_builder_under_asan_and_ubsan(tmp_path):
            os.path.join(ROOT, "raytracingrust_amd", "csrc", "rtr_scene.cpp")]
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-3000:]
-    r = subprocess.run([exe, os.path.join(ROOT, "data")], capture_output=True, text=True,
+    import numpy as np
+
+    from raytracingrust_amd.scene import write_pfm
+
+    y, x, c = np.meshgrid(np.arange(2), np.arange(3), np.arange(3), indexing="ij")
+    pfm = str(tmp_path / "sky.pfm")
+    write_pfm(pfm, (10.0 * y + x + 0.25 * c).astype(np.float32))
+    r = subprocess.run([exe, os.path.join(ROOT, "data"), pfm], capture_output=True, text=True,
                        env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1", UBSAN_OPTIONS="print_stacktrace=1"))
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.stdout[-2000:], r.stderr[-3000:])
