@@ -18,6 +18,7 @@
 // Errors: the reference panics; here they are std::runtime_error carrying the library's message.
 #pragma once
 
+#include <charconv>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -79,12 +80,26 @@ struct Lowered {
     }
 };
 
+// ---- writer helpers: the serde_json + typetag layout Scene::from_file reads --------------
+namespace jsonw {
+inline std::string num(float v) { // shortest decimal that parses back to the same f32, as serde_json (ryu) prints it
+    char buf[48];
+    auto r = std::to_chars(buf, buf + sizeof buf, v);
+    std::string t(buf, r.ptr);
+    if (t.find_first_of(".en") == std::string::npos) t += ".0"; // serde_json writes 1.0, not 1
+    return t;
+}
+inline std::string xyz(Vec3 v) { return "{\"x\": " + num(v.x) + ", \"y\": " + num(v.y) + ", \"z\": " + num(v.z) + "}"; }
+inline std::string rgb(Color c) { return "{\"r\": " + num(c.r) + ", \"g\": " + num(c.g) + ", \"b\": " + num(c.b) + "}"; }
+} // namespace jsonw
+
 // ---- materials (lib/materials.rs) ----------------------------------------------------------------------------
 class Material {
   public:
     virtual ~Material() = default;
     // writes this material into out[slot]; nested children are appended after the existing entries
     virtual void lower(std::vector<rtr_material> &out, size_t slot) const = 0;
+    virtual std::string to_json() const = 0; // the typetag object: {"type": "...", fields}
   protected:
     static rtr_material make(uint32_t kind, Color c, float param) {
         rtr_material m{};
@@ -97,30 +112,35 @@ class Lambertian : public Material { // materials.rs:18-42
     explicit Lambertian(Color albedo) : albedo(albedo) {}
     Color albedo;
     void lower(std::vector<rtr_material> &out, size_t slot) const override { out[slot] = make(RTR_MAT_LAMBERTIAN, albedo, 0); }
+    std::string to_json() const override { return "{\"type\": \"Lambertian\", \"albedo\": " + jsonw::rgb(albedo) + "}"; }
 };
 class Metal : public Material { // materials.rs:44-71
   public:
     Metal(Color albedo, float fuzz) : albedo(albedo), fuzz(fuzz) {}
     Color albedo; float fuzz;
     void lower(std::vector<rtr_material> &out, size_t slot) const override { out[slot] = make(RTR_MAT_METAL, albedo, fuzz); }
+    std::string to_json() const override { return "{\"type\": \"Metal\", \"albedo\": " + jsonw::rgb(albedo) + ", \"fuzz\": " + jsonw::num(fuzz) + "}"; }
 };
 class Emission : public Material { // materials.rs:73-91: colour pre-multiplied by strength
   public:
     Emission(Color c, float strength) : color{c.r * strength, c.g * strength, c.b * strength} {}
     Color color;
     void lower(std::vector<rtr_material> &out, size_t slot) const override { out[slot] = make(RTR_MAT_EMISSION, color, 0); }
+    std::string to_json() const override { return "{\"type\": \"Emission\", \"color\": " + jsonw::rgb(color) + "}"; }
 };
 class Dielectric : public Material { // materials.rs:93-139
   public:
     explicit Dielectric(float ir) : ir(ir) {}
     float ir;
     void lower(std::vector<rtr_material> &out, size_t slot) const override { out[slot] = make(RTR_MAT_DIELECTRIC, Color{0, 0, 0}, ir); }
+    std::string to_json() const override { return "{\"type\": \"Dielectric\", \"ir\": " + jsonw::num(ir) + "}"; }
 };
 class Isotropic : public Material { // volume.rs:75-88
   public:
     explicit Isotropic(Color c) : color(c) {}
     Color color;
     void lower(std::vector<rtr_material> &out, size_t slot) const override { out[slot] = make(RTR_MAT_ISOTROPIC, color, 0); }
+    std::string to_json() const override { return "{\"type\": \"Isotropic\", \"color\": " + jsonw::rgb(color) + "}"; }
 };
 class MixMaterial : public Material { // materials.rs:141-157: xi >= factor picks `first`
   public:
@@ -134,6 +154,9 @@ class MixMaterial : public Material { // materials.rs:141-157: xi >= factor pick
         size_t b = out.size(); out.emplace_back(); second->lower(out, b);
         out[slot].first = (uint32_t)a; out[slot].second = (uint32_t)b;
     }
+    std::string to_json() const override {
+        return "{\"type\": \"MixMaterial\", \"first\": " + first->to_json() + ", \"second\": " + second->to_json() + ", \"factor\": " + jsonw::num(factor) + "}";
+    }
 };
 
 // ---- objects -------------------------------------------------------------------------------------------------
@@ -142,6 +165,7 @@ class Object { // lib/core/traits.rs:18-21
     virtual ~Object() = default;
     virtual MaterialHandle material() const = 0;
     virtual void lower(Lowered &out) const = 0;
+    virtual std::string to_json() const = 0;
 };
 class Sphere : public Object { // objects.rs:15-20
   public:
@@ -153,6 +177,9 @@ class Sphere : public Object { // objects.rs:15-20
         s.material = (uint32_t)mat.index;
         out.objects.push_back(rtr_object{RTR_OBJ_SPHERE, (uint32_t)out.spheres.size()});
         out.spheres.push_back(s);
+    }
+    std::string to_json() const override {
+        return "{\"type\": \"Sphere\", \"center\": " + jsonw::xyz(center) + ", \"radius\": " + jsonw::num(radius) + ", \"material\": " + std::to_string(mat.index) + "}";
     }
 };
 
@@ -168,6 +195,9 @@ class Volume : public Object { // volume.rs:19-32 (sphere boundaries on the GPU 
         v.neg_inv_density = neg_inv_density;
         out.objects.push_back(rtr_object{RTR_OBJ_VOLUME, (uint32_t)out.volumes.size()});
         out.volumes.push_back(v);
+    }
+    std::string to_json() const override {
+        return "{\"type\": \"Volume\", \"boundary\": " + boundary.to_json() + ", \"neg_inv_density\": " + jsonw::num(neg_inv_density) + "}";
     }
 };
 
@@ -234,6 +264,7 @@ class Mesh : public Object { // mesh.rs:31-121
         out.objects.push_back(rtr_object{RTR_OBJ_MESH, (uint32_t)out.meshes.size()});
         out.meshes.push_back(m);
     }
+    std::string to_json() const override { throw std::runtime_error("Mesh cannot be serialized (the reference panics: mesh.rs:40-49)"); }
 };
 
 // ---- backgrounds (lib/backgrounds.rs) ------------------------------------------------------------------------
@@ -241,12 +272,14 @@ class Background {
   public:
     virtual ~Background() = default;
     virtual void lower(rtr_background &out) const = 0;
+    virtual std::string to_json() const = 0;
 };
 class UniformBackground : public Background {
   public:
     explicit UniformBackground(Color c) : color(c) {}
     Color color;
     void lower(rtr_background &o) const override { o = rtr_background{}; o.kind = RTR_BG_UNIFORM; o.a[0] = color.r; o.a[1] = color.g; o.a[2] = color.b; }
+    std::string to_json() const override { return "{\"type\": \"UniformBackground\", \"color\": " + jsonw::rgb(color) + "}"; }
 };
 class GradientBackground : public Background {
   public:
@@ -256,6 +289,7 @@ class GradientBackground : public Background {
         o = rtr_background{}; o.kind = RTR_BG_GRADIENT;
         o.a[0] = top.r; o.a[1] = top.g; o.a[2] = top.b; o.b[0] = bottom.r; o.b[1] = bottom.g; o.b[2] = bottom.b;
     }
+    std::string to_json() const override { return "{\"type\": \"GradientBackground\", \"top\": " + jsonw::rgb(top) + ", \"bottom\": " + jsonw::rgb(bottom) + "}"; }
 };
 class SkyMap : public Background { // backgrounds.rs:51-56: row-major texels, row 0 = top scanline
   public:
@@ -284,6 +318,11 @@ class SkyMap : public Background { // backgrounds.rs:51-56: row-major texels, ro
     }
     std::vector<float> image; uint32_t width, height;
     void lower(rtr_background &o) const override { o = rtr_background{}; o.kind = RTR_BG_SKYMAP; o.image = image.data(); o.width = width; o.height = height; }
+    std::string to_json() const override { // backgrounds.rs:51-56: the whole image inline
+        std::string t = "{\"type\": \"SkyMap\", \"image\": [";
+        for (size_t i = 0; i + 2 < image.size(); i += 3) { if (i) t += ", "; t += jsonw::rgb(Color{image[i], image[i + 1], image[i + 2]}); }
+        return t + "], \"width\": " + std::to_string(width) + ", \"height\": " + std::to_string(height) + "}";
+    }
 };
 
 // ---- a small JSON reader for scenes/*.json (serde_json + typetag layout) ---------------
@@ -343,6 +382,27 @@ class Scene {
     ObjectHandle add_object(std::unique_ptr<Object> o) { objects.push_back(std::move(o)); return ObjectHandle{objects.size() - 1}; }         // scene.rs:87-90
     MaterialHandle add_material(std::unique_ptr<Material> m) { materials_.push_back(std::move(m)); return MaterialHandle{materials_.size() - 1}; } // scene.rs:100-103
     const Material &material(MaterialHandle h) const { return *materials_.at(h.index); }
+    // The document Scene::from_file reads back (the reference derives Serialize: serde_json::to_string(&scene)).
+    std::string to_json() const {
+        static const char *modes[] = {"Full", "Clay", "Random", "Normal"};
+        std::string t = "{\n \"camera\": {\"lookfrom\": " + jsonw::xyz(camera.lookfrom) + ", \"lookat\": " + jsonw::xyz(camera.lookat) +
+                        ", \"vertical\": " + jsonw::xyz(camera.vertical) + ", \"vertical_fov\": " + jsonw::num(camera.vertical_fov) +
+                        ", \"aspect_ratio\": " + jsonw::num(camera.aspect_ratio) + "},\n";
+        t += " \"settings\": {\"samples_per_pixel\": " + std::to_string(settings.samples_per_pixel) + ", \"max_ray_depth\": " +
+             std::to_string((unsigned)settings.max_ray_depth) + ", \"clamp_indirect\": " + jsonw::num(settings.clamp_indirect) +
+             ", \"enable_multithreading\": " + (settings.enable_multithreading ? "true" : "false") + ", \"enable_bvh_tree\": " +
+             (settings.enable_bvh_tree ? "true" : "false") + ", \"mode\": \"" + modes[(uint32_t)settings.mode] + "\"},\n";
+        t += " \"background\": " + background->to_json() + ",\n \"objects\": [";
+        for (size_t i = 0; i < objects.size(); i++) t += (i ? ",\n  " : "\n  ") + objects[i]->to_json();
+        t += "\n ],\n \"materials\": [";
+        for (size_t i = 0; i < materials_.size(); i++) t += (i ? ",\n  " : "\n  ") + materials_[i]->to_json();
+        return t + "\n ]\n}\n";
+    }
+    void save(const std::string &path) const {
+        std::ofstream out(path);
+        if (!out) throw std::runtime_error("cannot write " + path);
+        out << to_json();
+    }
     size_t material_count() const { return materials_.size(); }
 
     // Scene::from_file (scene.rs:74-76).  settings.clamp_indirect is absent from both shipped scene files, which

@@ -426,6 +426,71 @@ class Scene:
                 raise ValueError(f"unknown object type {t!r}")
         return scene
 
+    # -- the writer side of the same layout (the reference derives Serialize: `serde_json::to_string(&scene)`) -----
+    def to_dict(self) -> dict:
+        """The serde + typetag document of this scene (SURVEY.md appendix C): what `Scene::from_file` reads back.
+        f32 fields are written in their shortest round-tripping decimal form, as serde_json (ryu) prints them.
+        A Mesh cannot be serialised: the reference's `Serialize for Mesh` panics (mesh.rs:40-49)."""
+
+        def num(x) -> float:
+            return float(str(np.float32(x)))  # shortest decimal that parses back to the same f32
+
+        def xyz(v) -> dict:
+            return {"x": num(v[0]), "y": num(v[1]), "z": num(v[2])}
+
+        def rgb(v) -> dict:
+            return {"r": num(v[0]), "g": num(v[1]), "b": num(v[2])}
+
+        def material(m: Material) -> dict:
+            if isinstance(m, Lambertian):
+                return {"type": "Lambertian", "albedo": rgb(m.albedo)}
+            if isinstance(m, Metal):
+                return {"type": "Metal", "albedo": rgb(m.albedo), "fuzz": num(m.fuzz)}
+            if isinstance(m, Emission):
+                return {"type": "Emission", "color": rgb(m.color)}  # strength is pre-multiplied (materials.rs:79-83)
+            if isinstance(m, Dielectric):
+                return {"type": "Dielectric", "ir": num(m.ir)}
+            if isinstance(m, MixMaterial):
+                return {"type": "MixMaterial", "first": material(m.first), "second": material(m.second), "factor": num(m.factor)}
+            if isinstance(m, Isotropic):
+                return {"type": "Isotropic", "color": rgb(m.color)}
+            raise TypeError(f"unknown material {type(m).__name__}")
+
+        def sphere(o: Sphere) -> dict:
+            return {"type": "Sphere", "center": xyz(o.center), "radius": num(o.radius), "material": int(o.material)}
+
+        objects = []
+        for o in self.objects:
+            if isinstance(o, Sphere):
+                objects.append(sphere(o))
+            elif isinstance(o, Volume):
+                objects.append({"type": "Volume", "boundary": sphere(o.boundary), "neg_inv_density": num(o.neg_inv_density)})
+            else:
+                raise ValueError("Mesh cannot be serialized (the reference panics: mesh.rs:40-49)")
+        bg = self.background
+        if isinstance(bg, UniformBackground):
+            background = {"type": "UniformBackground", "color": rgb(bg.color)}
+        elif isinstance(bg, GradientBackground):
+            background = {"type": "GradientBackground", "top": rgb(bg.top), "bottom": rgb(bg.bottom)}
+        else:  # backgrounds.rs:51-56: the whole image inline
+            background = {"type": "SkyMap", "image": [rgb(t) for t in bg.image.reshape(-1, 3)],
+                          "width": bg.width, "height": bg.height}
+        c, st = self.camera, self.settings
+        return {
+            "camera": {"lookfrom": xyz(c.lookfrom), "lookat": xyz(c.lookat), "vertical": xyz(c.vertical),
+                       "vertical_fov": num(c.vertical_fov), "aspect_ratio": num(c.aspect_ratio)},
+            "settings": {"samples_per_pixel": int(st.samples_per_pixel), "max_ray_depth": int(st.max_ray_depth),
+                         "clamp_indirect": num(st.clamp_indirect), "enable_multithreading": bool(st.enable_multithreading),
+                         "enable_bvh_tree": bool(st.enable_bvh_tree), "mode": RenderMode(st.mode).name},
+            "background": background,
+            "objects": objects,
+            "materials": [material(m) for m in self.materials],
+        }
+
+    def to_file(self, path: str) -> None:
+        with open(path, "w") as fh:
+            json.dump(self.to_dict(), fh, indent=2)
+
     @staticmethod
     def _background_from_dict(b: dict) -> Background:
         t = b["type"]

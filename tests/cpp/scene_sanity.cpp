@@ -92,6 +92,24 @@ int main(int argc, char **argv) {
         s.add_object(std::make_unique<Sphere>(Vec3{0, 0, -1}, 0.5f, lam));
         check_scene(s, "single");
     }
+    { // JSON writer: what Scene::to_json writes, Scene::from_file reads back to the same lowered records
+        const std::string tmp = std::string(argc > 3 ? argv[3] : "/tmp") + "/scene_sanity_roundtrip.json";
+        for (const char *name : {"/scenes/simple.json", "/scenes/benchmark.json"}) {
+            Scene a = Scene::from_file(data + name);
+            a.objects.size() > 3 ? (void)a.add_material(std::make_unique<MixMaterial>(std::make_unique<Metal>(Color{0.1f, 0.2f, 0.3f}, 0.25f), std::make_unique<Dielectric>(1.5f), 0.3f)) : (void)0;
+            a.add_object(std::make_unique<Volume>(Sphere(Vec3{0, 1, 0}, 2.5f, MaterialHandle{0}), 0.7f));
+            a.save(tmp);
+            Scene b = Scene::from_file(tmp);
+            CHECK(b.to_json() == a.to_json());
+            Lowered la, lb;
+            a.lower(la); b.lower(lb);
+            CHECK(la.spheres.size() == lb.spheres.size() && la.materials.size() == lb.materials.size() && la.volumes.size() == lb.volumes.size());
+            CHECK(la.spheres.empty() || std::memcmp(la.spheres.data(), lb.spheres.data(), la.spheres.size() * sizeof(rtr_sphere)) == 0);
+            CHECK(la.materials.empty() || std::memcmp(la.materials.data(), lb.materials.data(), la.materials.size() * sizeof(rtr_material)) == 0);
+            CHECK(la.volumes.empty() || std::memcmp(la.volumes.data(), lb.volumes.data(), la.volumes.size() * sizeof(rtr_volume)) == 0);
+        }
+        std::printf("%s", Scene::from_file(data + "/scenes/benchmark.json").to_json().c_str()); // compared with the Python writer
+    }
     if (argc > 2) { // a little-endian colour PFM written by the Python side: 3 x 2 texels, texel (x, y) = 10*y + x + 0.25*c
         auto sky = SkyMap::from_pfm(argv[2]);
         CHECK(sky->width == 3 && sky->height == 2);
