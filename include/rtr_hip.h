@@ -44,7 +44,8 @@
 extern "C" {
 #endif
 
-#define RTR_ABI_VERSION 2
+/* 2: volumes, rtr_set_option.  3: rtr_selftest_div, options "leaf_pairs"; structs unchanged since 2. */
+#define RTR_ABI_VERSION 3
 
 typedef enum rtr_status {
     RTR_OK = 0,

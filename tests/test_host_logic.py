@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), f"librtr_hip.so does not export {name}"
     bound = {n for n, _, _ in _capi.SYMBOLS}
     assert declared == bound, declared ^ bound
-    assert _capi.load().rtr_abi_version() == 2
+    assert _capi.load().rtr_abi_version() == 3
 
 
 def test_struct_layouts_match_the_header():
