@@ -97,6 +97,7 @@ struct RenderParams {
     uint32_t sphere_regs;   // linear sphere world: spheres held in scalar registers (0 = generic loop)
     uint32_t lds_materials; // number of material records staged in LDS (0 = read from HBM/L1)
     uint32_t has_meshes;    // the scene holds triangles: tree kernels instantiated with the unconditional slab tests
+    uint32_t resumable_walk; // WORLD_BVH: k_render_bvh (per-lane walk state machine) instead of k_render
     uint32_t has_volumes;   // the scene holds Volume objects: kernels instantiated with the visit-order rules
     const DevNode *nodes;
     const DevLeafHot *leaf_hot;

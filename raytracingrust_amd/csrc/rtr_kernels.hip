@@ -737,6 +737,99 @@ RTR_DEV V3 background(const RenderParams &p, const Ray &r) {
     return mk(texel.x, texel.y, texel.z);
 }
 
+// The part of trace_ray (render.rs:38-58) after world.hit: background on a miss, else the material's scatter.
+// Returns `done` (the path ended: `term` is its terminal radiance) or false with the next segment in `ray`.
+RTR_DEV bool shade_segment(const RenderParams &p, bool was_hit, const Hit &h, Ray &ray, Rng &rng, const uint32_t *lds_mats,
+                           uint32_t *chain, uint32_t lane, uint32_t &nchain, uint32_t &depth, V3 &term) {
+    bool done;
+    if (!was_hit) {
+        term = background(p, ray);
+        done = true;
+    } else if (p.mode == 3u) { // RenderMode::Normal, render.rs:42-45
+        V3 n = scale(add(normalize(h.normal), mk(1.0f, 1.0f, 1.0f)), 0.5f);
+        term = n;
+        done = true;
+    } else if (p.mode == 2u) { // RenderMode::Random, render.rs:46-48
+        term = mk(0.0f, 0.0f, 0.0f);
+        done = true;
+    } else {
+        uint32_t kind, mid = h.material;
+        float param = 0.0f;
+        V3 rgb = mk(0.8f, 0.8f, 0.8f);
+        if (p.mode == 1u) { // RenderMode::Clay: Lambertian(0.8) (render.rs:41)
+            kind = 0u; mid = kChainClay;
+        } else {
+            // MixMaterial::scatter (materials.rs:148-157): xi >= factor -> first
+            for (;;) {
+                float4 q0, q1;
+                material_load(p, lds_mats, mid, q0, q1);
+                kind = __float_as_uint(q1.x);
+                rgb = mk(q0.x, q0.y, q0.z);
+                param = q0.w;
+                if (kind != 4u) break;
+                mid = (rng_unit(rng) >= param) ? __float_as_uint(q1.y) : __float_as_uint(q1.z);
+            }
+        }
+        bool scattered = true;
+        V3 ndir = h.normal;
+        // Lambertian, Metal and Isotropic all start from one rejection-sampled point of the unit ball
+        // (sample.rs:43-51) and it is their first draw after the mix walk, so the loop is run ONCE for all
+        // three kinds (one divergent loop per segment instead of one per material kind).
+        V3 sv = mk(0.0f, 0.0f, 0.0f);
+        if (kind == 0u || kind == 1u || kind == 5u) {
+            float m2;
+            sv = sample_unit_ball(rng, m2);
+            if (kind != 5u) sv = scale(sv, 1.0f / rt_sqrt(m2)); // sample_unit_sphere_surface, sample.rs:66-70
+        }
+        if (kind == 0u) { // Lambertian, materials.rs:31-41
+            ndir = add(h.normal, sv);
+            if (near_zero(ndir)) ndir = h.normal;
+        } else if (kind == 1u) { // Metal, materials.rs:58-70
+            V3 reflected = normalize(reflect(ray.d, h.normal));
+            ndir = add(reflected, scale(sv, param));
+            if (!(dot(ndir, h.normal) > 0.0f)) { scattered = false; term = mk(0.0f, 0.0f, 0.0f); }
+        } else if (kind == 2u) { // Emission, materials.rs:86-91
+            scattered = false; term = rgb;
+        } else if (kind == 3u) { // Dielectric, materials.rs:111-138
+#ifndef RTR_X_NO_DIELECTRIC_CONSTANTS
+            // 1/ir and the two Schlick r0^2 values are constants of the material, divided once on the host
+            // (rtr_scene.cpp) into the record's spare words: re-read here rather than kept live across the sampler
+            float4 dq0, dq1;
+            material_load(p, lds_mats, mid, dq0, dq1);
+            const float ratio = h.front_face ? dq1.y : param;
+            const float r0sq = h.front_face ? dq1.z : dq1.w;
+#else
+            float ratio = h.front_face ? 1.0f / param : param;
+#endif
+            V3 unit = normalize(ray.d);
+            float cos_theta = fminf(dot(h.normal, neg(unit)), 1.0f);
+            float sin_theta = rt_sqrt(1.0f - cos_theta * cos_theta);
+            bool cannot_refract = (ratio * sin_theta) > 1.0f;
+            bool refl = cannot_refract;
+#ifndef RTR_X_NO_DIELECTRIC_CONSTANTS
+            if (!refl) refl = reflectance_r0(cos_theta, r0sq) > rng_unit(rng); // no draw on TIR (short-circuit ||)
+#else
+            if (!refl) refl = reflectance(cos_theta, ratio) > rng_unit(rng); // no draw on TIR (short-circuit ||)
+#endif
+            ndir = refl ? reflect(unit, h.normal) : refract(unit, h.normal, ratio);
+            mid = 0xFFFFFFFEu; // attenuation (1,1,1): x*1 == x exactly, nothing to replay
+        } else { // Isotropic, volume.rs:80-88: the un-normalised ball sample is the direction
+            ndir = sv;
+        }
+        if (scattered) {
+            if (mid != 0xFFFFFFFEu) { chain[nchain * 64u + lane] = mid; nchain++; }
+            ray.o = h.point;
+            ray.d = ndir;
+            depth++;
+            done = depth >= p.max_depth; // render.rs:34-36
+            term = mk(0.0f, 0.0f, 0.0f);
+        } else {
+            done = true;
+        }
+    }
+    return done;
+}
+
 // One wave = one 8x8 tile.  LDS (dynamic, 16-byte aligned pieces):
 //   [chain: max_depth x 64 u32][stack refs: cap x 64][stack t: cap x 64][spheres: NS x 8][materials: lds_mats x 8]
 #ifndef RTR_X_WAVES_PER_EU
@@ -854,93 +947,7 @@ __global__ __launch_bounds__(64, RTR_X_WAVES_PER_EU) void k_render(const RenderP
         V3 term;
         const bool was_hit = world_hit<WORLD, NS, VOL, MESH>(p, ray, h, stk_ref, stk_t, lane, sr, lds_spheres, rng);
         RTR_STAMP(0)
-        if (!was_hit) {
-            term = background(p, ray);
-            done = true;
-        } else if (p.mode == 3u) { // RenderMode::Normal, render.rs:42-45
-            V3 n = scale(add(normalize(h.normal), mk(1.0f, 1.0f, 1.0f)), 0.5f);
-            term = n;
-            done = true;
-        } else if (p.mode == 2u) { // RenderMode::Random, render.rs:46-48
-            term = mk(0.0f, 0.0f, 0.0f);
-            done = true;
-        } else {
-            uint32_t kind, mid = h.material;
-            float param = 0.0f;
-            V3 rgb = mk(0.8f, 0.8f, 0.8f);
-            if (p.mode == 1u) { // RenderMode::Clay: Lambertian(0.8) (render.rs:41)
-                kind = 0u; mid = kChainClay;
-            } else {
-                // MixMaterial::scatter (materials.rs:148-157): xi >= factor -> first
-                for (;;) {
-                    float4 q0, q1;
-                    material_load(p, lds_mats, mid, q0, q1);
-                    kind = __float_as_uint(q1.x);
-                    rgb = mk(q0.x, q0.y, q0.z);
-                    param = q0.w;
-                    if (kind != 4u) break;
-                    mid = (rng_unit(rng) >= param) ? __float_as_uint(q1.y) : __float_as_uint(q1.z);
-                }
-            }
-            bool scattered = true;
-            V3 ndir = h.normal;
-            RTR_STAMP(1)
-            // Lambertian, Metal and Isotropic all start from one rejection-sampled point of the unit ball
-            // (sample.rs:43-51) and it is their first draw after the mix walk, so the loop is run ONCE for all
-            // three kinds (one divergent loop per segment instead of one per material kind).
-            V3 sv = mk(0.0f, 0.0f, 0.0f);
-            if (kind == 0u || kind == 1u || kind == 5u) {
-                float m2;
-                sv = sample_unit_ball(rng, m2);
-                if (kind != 5u) sv = scale(sv, 1.0f / rt_sqrt(m2)); // sample_unit_sphere_surface, sample.rs:66-70
-            }
-            RTR_STAMP(2)
-            if (kind == 0u) { // Lambertian, materials.rs:31-41
-                ndir = add(h.normal, sv);
-                if (near_zero(ndir)) ndir = h.normal;
-            } else if (kind == 1u) { // Metal, materials.rs:58-70
-                V3 reflected = normalize(reflect(ray.d, h.normal));
-                ndir = add(reflected, scale(sv, param));
-                if (!(dot(ndir, h.normal) > 0.0f)) { scattered = false; term = mk(0.0f, 0.0f, 0.0f); }
-            } else if (kind == 2u) { // Emission, materials.rs:86-91
-                scattered = false; term = rgb;
-            } else if (kind == 3u) { // Dielectric, materials.rs:111-138
-#ifndef RTR_X_NO_DIELECTRIC_CONSTANTS
-                // 1/ir and the two Schlick r0^2 values are constants of the material, divided once on the host
-                // (rtr_scene.cpp) into the record's spare words: re-read here rather than kept live across the sampler
-                float4 dq0, dq1;
-                material_load(p, lds_mats, mid, dq0, dq1);
-                const float ratio = h.front_face ? dq1.y : param;
-                const float r0sq = h.front_face ? dq1.z : dq1.w;
-#else
-                float ratio = h.front_face ? 1.0f / param : param;
-#endif
-                V3 unit = normalize(ray.d);
-                float cos_theta = fminf(dot(h.normal, neg(unit)), 1.0f);
-                float sin_theta = rt_sqrt(1.0f - cos_theta * cos_theta);
-                bool cannot_refract = (ratio * sin_theta) > 1.0f;
-                bool refl = cannot_refract;
-#ifndef RTR_X_NO_DIELECTRIC_CONSTANTS
-                if (!refl) refl = reflectance_r0(cos_theta, r0sq) > rng_unit(rng); // no draw on TIR (short-circuit ||)
-#else
-                if (!refl) refl = reflectance(cos_theta, ratio) > rng_unit(rng); // no draw on TIR (short-circuit ||)
-#endif
-                ndir = refl ? reflect(unit, h.normal) : refract(unit, h.normal, ratio);
-                mid = 0xFFFFFFFEu; // attenuation (1,1,1): x*1 == x exactly, nothing to replay
-            } else { // Isotropic, volume.rs:80-88: the un-normalised ball sample is the direction
-                ndir = sv;
-            }
-            if (scattered) {
-                if (mid != 0xFFFFFFFEu) { chain[nchain * 64u + lane] = mid; nchain++; }
-                ray.o = h.point;
-                ray.d = ndir;
-                depth++;
-                done = depth >= p.max_depth; // render.rs:34-36
-                term = mk(0.0f, 0.0f, 0.0f);
-            } else {
-                done = true;
-            }
-        }
+        done = shade_segment(p, was_hit, h, ray, rng, lds_mats, chain, lane, nchain, depth, term);
         RTR_STAMP(1)
         if (done) {
             // attenuation * (attenuation * (... * terminal)), render.rs:52
@@ -996,6 +1003,221 @@ __global__ __launch_bounds__(64, RTR_X_WAVES_PER_EU) void k_render(const RenderP
     }
 #endif
     // one atomic per wave
+    unsigned long long total = nseg;
+    for (int off = 32; off > 0; off >>= 1) total += __shfl_xor(total, off, 64);
+    if (lane == 0 && total) atomicAdd(p.counter, total);
+}
+
+// ---- WORLD_BVH with a resumable walk -------------------------------------------------------------------------------
+// In k_render a wave leaves world.hit only when its slowest lane has finished its walk: rays that need 10 trips wait
+// for rays that need 60 (C4: 19 % of VALU lane-cycles active).  Here the walk is a per-lane state machine inside the
+// main loop: lanes take traversal trips until no more than `1/RTR_TREE_QUORUM_DEN` of the wave's live lanes are still
+// walking, then the lanes whose walk has ended shade, scatter or regenerate together and rejoin with a fresh walk, while
+// the late walkers simply keep their state.  Every lane executes exactly the operations it executes in k_render, in the
+// same order (its random stream included), so the frame is bit-identical; only the interleaving between lanes changes.
+#ifndef RTR_TREE_QUORUM_NUM
+#define RTR_TREE_QUORUM_NUM 1
+#endif
+#ifndef RTR_TREE_QUORUM_DEN
+#define RTR_TREE_QUORUM_DEN 2
+#endif
+template <bool VOL, bool MESH>
+__attribute__((amdgpu_num_sgpr(96)))
+__global__ __launch_bounds__(64, RTR_X_WAVES_PER_EU) void k_render_bvh(const RenderParams p) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t tile = blockIdx.x * p.n_shards + p.shard;
+    if (tile >= p.tiles_total) return;
+    uint32_t *chain = lds;
+    uint32_t *stk_ref = lds + p.max_depth * 64u;
+    float *stk_t = reinterpret_cast<float *>(stk_ref + p.stack_cap * 64u);
+    uint32_t *lds_mat_base = reinterpret_cast<uint32_t *>(stk_t + p.stack_cap * 64u);
+    const uint32_t *lds_mats = p.lds_materials ? lds_mat_base : nullptr;
+    if (p.lds_materials)
+        for (uint32_t i = lane; i < p.lds_materials * 8u; i += 64u) lds_mat_base[i] = reinterpret_cast<const uint32_t *>(p.materials)[i];
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+
+    const uint32_t tx = tile % p.tiles_x, ty = tile / p.tiles_x;
+    const uint32_t x = tx * 8u + (lane & 7u), y = ty * 8u + (lane >> 3);
+    const bool inside = x < p.width && y < p.height;
+    const uint32_t pixel = y * p.width + x;
+    const float fx = (float)x, fy = (float)y;
+    const V3 cam_o = ld3(p.cam_origin), cam_h = ld3(p.cam_horizontal), cam_v = ld3(p.cam_vertical), cam_llc = ld3(p.cam_llc);
+    const uint32_t hp = hash32(pixel ^ p.seed_lo);
+    Rng rng;
+    rng.inc = (hash32(hp + p.seed_hi) << 1) | 1u;
+    rng.state = 0u;
+
+    V3 acc = mk(0.0f, 0.0f, 0.0f);
+    uint32_t nseg = 0;
+    const uint32_t spp = (inside && p.max_depth > 0u) ? p.sample_begin + p.sample_count : 0u;
+    uint32_t s = p.sample_begin, depth = 0, nchain = 0;
+    Ray ray;
+    ray.o = cam_o; ray.d = cam_o;
+    const SharedDiv div_w = shared_div_prepare(p.width_m1), div_h = shared_div_prepare(p.height_m1);
+    const bool uv_fast = div_w.ok && div_h.ok;
+    auto start_sample = [&](uint32_t si) { // render.rs:80-90, camera.rs:19-24 (as in k_render)
+        rng.state = hash32(hp + si * 0x9E3779B9u);
+        float u = fx + rng_unit_inclusive(rng);
+        float v = fy + rng_unit_inclusive(rng);
+        if (uv_fast) {
+            u = shared_div(u, div_w.d, div_w.r1);
+            v = shared_div(v, div_h.d, div_h.r1);
+        } else {
+            u = u / p.width_m1;
+            v = v / p.height_m1;
+        }
+        ray.o = cam_o;
+        ray.d = sub(sub(add(cam_llc, scale(cam_h, u)), scale(cam_v, v)), cam_o);
+        depth = 0; nchain = 0;
+    };
+
+    // the walk's per-lane state (world_hit + traverse of k_render, unrolled into the loop below)
+    uint32_t cur = REF_NONE, sp = 0;
+    Best best;
+    best.leaf = REF_NONE; best.t = __builtin_inff(); best.u = 0.0f; best.v = 0.0f;
+    V3 inv = mk(0.0f, 0.0f, 0.0f);
+    float a = 0.0f;
+    bool walking = false;
+    auto begin_segment = [&]() { // the head of world_hit<WORLD_BVH>
+        nseg++;
+        a = dot(ray.d, ray.d);
+        inv = mk(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z);
+        best.leaf = REF_NONE; best.t = __builtin_inff(); best.u = 0.0f; best.v = 0.0f;
+        const uint32_t root = p.root_ref;
+        bool go = root != REF_NONE;
+        if (go && (root & (REF_LEAF | REF_PAIR)) != REF_LEAF) {
+            float e;
+            go = slab(p.root_box, p.root_box + 3, ray, inv, __builtin_inff(), e);
+        }
+        cur = root; sp = 0;
+        walking = go;
+    };
+    bool alive = s < spp;
+    if (alive) { start_sample(s); begin_segment(); }
+
+    for (;;) {
+        const uint64_t alive_mask = __ballot(alive);
+        if (alive_mask == 0ull) break;
+        const uint32_t quorum = (uint32_t)__popcll(alive_mask) * RTR_TREE_QUORUM_NUM / RTR_TREE_QUORUM_DEN;
+        // ---- walk: one trip per iteration for every lane still walking (the body of `traverse`) ----
+        while ((uint32_t)__popcll(__ballot(walking)) > quorum) {
+            if (walking) {
+                bool pop = false;
+                if (cur & REF_LEAF) {
+                    test_leaf<VOL>(p, cur & ~REF_PAIR, ray, a, best, rng);
+                    pop = !(cur & REF_PAIR);
+                    cur = (cur & ~REF_PAIR) + 1u;
+                } else {
+                    const float4 *nq = reinterpret_cast<const float4 *>(p.nodes + cur);
+                    float4 q0 = nq[0], q1 = nq[1], q2 = nq[2], q3 = nq[3];
+                    gather_fence(q0, q1, q2, q3);
+                    float lmin[3] = {q0.x, q0.y, q0.z}, lmax[3] = {q0.w, q1.x, q1.y};
+                    float rmin[3] = {q1.z, q1.w, q2.x}, rmax[3] = {q2.y, q2.z, q2.w};
+                    uint32_t l = __float_as_uint(q3.x), rr = __float_as_uint(q3.y);
+                    const uint32_t flags = __float_as_uint(q3.z);
+                    const bool lvol = VOL && (flags & NODE_LVOL), rvol = VOL && (flags & NODE_RVOL);
+                    bool hl = l != REF_NONE, hr = rr != REF_NONE;
+                    float el = 0.0f, er = 0.0f;
+                    if constexpr (MESH) {
+                        float tl, tr;
+                        const bool sl = slab(lmin, lmax, ray, inv, __builtin_inff(), tl);
+                        const bool sr = slab(rmin, rmax, ray, inv, __builtin_inff(), tr);
+                        const bool gl = (l & (REF_LEAF | REF_PAIR)) != REF_LEAF;
+                        const bool gr = (rr & (REF_LEAF | REF_PAIR)) != REF_LEAF;
+                        el = gl ? tl : 0.0f;
+                        er = gr ? tr : 0.0f;
+                        hl = hl && (!gl || (sl && (lvol || !(tl > best.t))));
+                        hr = hr && (!gr || (sr && (rvol || !(tr > best.t))));
+                    } else {
+                        if (hl && (l & (REF_LEAF | REF_PAIR)) != REF_LEAF) {
+                            hl = slab(lmin, lmax, ray, inv, __builtin_inff(), el);
+                            if (!lvol && el > best.t) hl = false;
+                        }
+                        if (hr && (rr & (REF_LEAF | REF_PAIR)) != REF_LEAF) {
+                            hr = slab(rmin, rmax, ray, inv, __builtin_inff(), er);
+                            if (!rvol && er > best.t) hr = false;
+                        }
+                    }
+                    if (hl && hr) {
+                        bool sw = er < el;
+                        if (lvol && rvol) sw = false;
+                        uint32_t second = sw ? l : rr;
+                        float esecond = sw ? el : er;
+                        if (sw ? lvol : rvol) esecond = -__builtin_inff();
+                        cur = sw ? rr : l;
+                        stk_ref[sp * 64 + lane] = second;
+                        stk_t[sp * 64 + lane] = esecond;
+                        sp++;
+                    } else if (hl) {
+                        cur = l;
+                    } else if (hr) {
+                        cur = rr;
+                    } else {
+                        pop = true;
+                    }
+                }
+                if (pop) {
+                    bool got = false;
+                    while (sp > 0) {
+                        sp--;
+                        uint32_t c = stk_ref[sp * 64 + lane];
+                        float e = stk_t[sp * 64 + lane];
+                        if (e > best.t) continue;
+                        cur = c;
+                        got = true;
+                        break;
+                    }
+                    if (!got) walking = false;
+                }
+            }
+        }
+        // ---- the lanes whose walk has ended: the rest of trace_ray, then the next segment or the next sample ----
+        if (alive && !walking) {
+            Hit h;
+            const bool was_hit = best.leaf != REF_NONE;
+            if (was_hit) finish_leaf<VOL>(p, best, ray, h);
+            V3 term;
+            const bool done = shade_segment(p, was_hit, h, ray, rng, lds_mats, chain, lane, nchain, depth, term);
+            if (done) {
+                while (nchain > 0u) { // render.rs:52
+                    nchain--;
+                    term = mul(material_rgb(p, lds_mats, chain[nchain * 64u + lane]), term);
+                }
+                const float hi = p.clamp_indirect; // render.rs:95-97
+                if (term.x < 0.0f) term.x = 0.0f;
+                if (term.x > hi) term.x = hi;
+                if (term.y < 0.0f) term.y = 0.0f;
+                if (term.y > hi) term.y = hi;
+                if (term.z < 0.0f) term.z = 0.0f;
+                if (term.z > hi) term.z = hi;
+                acc = add(acc, term);
+                s++;
+                if (s < spp) start_sample(s);
+                else alive = false;
+            }
+            if (alive) begin_segment();
+        }
+    }
+
+    if (inside) {
+        if (p.sum_rgba) reinterpret_cast<float4 *>(p.sum_rgba)[pixel] = make_float4(acc.x, acc.y, acc.z, 0.0f);
+        if (p.rgba8 || p.mean_rgb) { // render.rs:103-110
+            const float n = (float)p.spp;
+            V3 mean = mk(acc.x / n, acc.y / n, acc.z / n);
+            if (p.mean_rgb) {
+                p.mean_rgb[3ull * pixel + 0] = mean.x;
+                p.mean_rgb[3ull * pixel + 1] = mean.y;
+                p.mean_rgb[3ull * pixel + 2] = mean.z;
+            }
+            if (p.rgba8) {
+                uint32_t r8 = sat_u8(sqrtf(mean.x) * 255.0f), g8 = sat_u8(sqrtf(mean.y) * 255.0f),
+                         b8 = sat_u8(sqrtf(mean.z) * 255.0f);
+                reinterpret_cast<uint32_t *>(p.rgba8)[pixel] = r8 | (g8 << 8) | (b8 << 16) | (255u << 24);
+            }
+        }
+    }
     unsigned long long total = nseg;
     for (int off = 32; off > 0; off >>= 1) total += __shfl_xor(total, off, 64);
     if (lane == 0 && total) atomicAdd(p.counter, total);
@@ -1079,6 +1301,13 @@ hipError_t launch_render(const RenderParams &p, uint32_t grid, uint32_t lds_byte
         break;
     case WORLD_BVH: // Volume leaves need the reference's visit set and order: a separate instantiation pays for it
         // ... and scenes with meshes get the traversal with unconditional slab tests (see `traverse`)
+        if (p.resumable_walk) {
+            if (p.has_volumes && p.has_meshes) hipLaunchKernelGGL((k_render_bvh<true, true>), dim3(grid), dim3(64), lds_bytes, stream, p);
+            else if (p.has_volumes) hipLaunchKernelGGL((k_render_bvh<true, false>), dim3(grid), dim3(64), lds_bytes, stream, p);
+            else if (p.has_meshes) hipLaunchKernelGGL((k_render_bvh<false, true>), dim3(grid), dim3(64), lds_bytes, stream, p);
+            else hipLaunchKernelGGL((k_render_bvh<false, false>), dim3(grid), dim3(64), lds_bytes, stream, p);
+            break;
+        }
         if (p.has_volumes && p.has_meshes) hipLaunchKernelGGL((k_render<WORLD_BVH, 0, true, true>), dim3(grid), dim3(64), lds_bytes, stream, p);
         else if (p.has_volumes) hipLaunchKernelGGL((k_render<WORLD_BVH, 0, true, false>), dim3(grid), dim3(64), lds_bytes, stream, p);
         else if (p.has_meshes) hipLaunchKernelGGL((k_render<WORLD_BVH, 0, false, true>), dim3(grid), dim3(64), lds_bytes, stream, p);
@@ -1102,7 +1331,10 @@ hipError_t launch_resolve(const float *sum_rgba, uint32_t spp, uint32_t n_pixels
 hipError_t render_kernel_attributes(const RenderParams &p, int *vgprs, int *static_lds) {
     hipFuncAttributes attr;
     const void *fn;
-    if (p.world == WORLD_BVH)
+    if (p.world == WORLD_BVH && p.resumable_walk)
+        fn = p.has_volumes ? (p.has_meshes ? reinterpret_cast<const void *>(k_render_bvh<true, true>) : reinterpret_cast<const void *>(k_render_bvh<true, false>))
+                           : (p.has_meshes ? reinterpret_cast<const void *>(k_render_bvh<false, true>) : reinterpret_cast<const void *>(k_render_bvh<false, false>));
+    else if (p.world == WORLD_BVH)
         fn = p.has_volumes ? (p.has_meshes ? reinterpret_cast<const void *>(k_render<WORLD_BVH, 0, true, true>)
                                            : reinterpret_cast<const void *>(k_render<WORLD_BVH, 0, true, false>))
                            : (p.has_meshes ? reinterpret_cast<const void *>(k_render<WORLD_BVH, 0, false, true>)

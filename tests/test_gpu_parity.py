@@ -501,3 +501,30 @@ def test_concurrent_calls_on_one_context_serialise():
     for seed in range(4):
         assert np.array_equal(got[seed][0], want[seed][0])
         assert np.array_equal(got[seed][1].view(np.uint32), want[seed][1].view(np.uint32))
+
+
+@pytest.mark.parametrize("builder,w,h", [(lambda: house_scene(2), 160, 90), (lambda: simple_scene(4), 128, 128),
+                                         (lambda: monkey_scene(3, material=rt.Dielectric(1.5)), 128, 72),
+                                         (lambda: benchmark_scene(4, enable_bvh_tree=True), 128, 72),
+                                         (lambda: _fog_scene(True, two_volumes=True), 96, 64)])
+def test_tree_kernels_agree_bit_for_bit(builder, w, h):
+    """Option tree_kernel: the wave-synchronous walk (k_render) and the resumable per-lane walk (k_render_bvh) execute
+    the same operations per lane in the same order, so their frames must be identical to the last bit -- and equal the
+    oracle's."""
+    scene = builder()
+    frames = {}
+    with rt.Renderer(0) as r:
+        r.upload_scene(scene)
+        for kernel in ("wave", "resumable", "auto"):
+            r.set_option("tree_kernel", kernel)
+            rgba, mean = r.render(w, h, seed=77, want_rgba8=True, want_mean=True)
+            frames[kernel] = (rgba, mean.view(np.uint32).copy(), r.stats().segments)
+        with pytest.raises(rt.RtrError):
+            r.set_option("tree_kernel", "fast")
+    for kernel in ("resumable", "auto"):
+        assert frames[kernel][2] == frames["wave"][2]
+        assert np.array_equal(frames[kernel][0], frames["wave"][0]) and np.array_equal(frames[kernel][1], frames["wave"][1])
+    o_rgba, o_mean, o_st = pyoracle.OracleScene(scene, trig_mode=pyoracle.TRIG_POLY).render(w, h, 77, threads=0)
+    assert o_st.segments == frames["wave"][2]
+    c = compare(frames["resumable"][1].view(np.float32), frames["resumable"][0], o_mean, o_rgba)
+    assert max(c["rel_l2"]) <= TOL and c["max_u8_delta"] <= 1, c
