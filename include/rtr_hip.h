@@ -205,7 +205,7 @@ int rtr_abi_version(void);
  *                 tree when enable_bvh_tree is set.  "wave": a wave returns from world.hit when its slowest lane has
  *                 finished.  "resumable": the walk is a per-lane state machine inside the main loop, so lanes that are
  *                 done shade and start their next ray while the others keep walking.  Same per-lane operations in the
- *                 same order: bit-identical frames.  "auto" takes "resumable" for trees at least 8 node records deep. */
+ *                 same order: bit-identical frames.  "auto" takes "resumable" for scenes that hold meshes. */
 int rtr_set_option(rtr_context *ctx, const char *name, const char *value);
 /* Lower + build + flatten + copy to HBM.  Replaces any previous scene of the context. */
 int rtr_upload_scene(rtr_context *ctx, const rtr_scene_desc *scene);
