@@ -503,10 +503,26 @@ def test_concurrent_calls_on_one_context_serialise():
         assert np.array_equal(got[seed][1].view(np.uint32), want[seed][1].view(np.uint32))
 
 
+def _tiny_tree_scene(n):
+    """BVH world over 0..3 spheres: BvhNode::None, a bare leaf as root (no box at all, bvh.rs:54), a leaf pair, and
+    a Split over a leaf and a pair."""
+    s = rt.Scene()
+    s.settings.samples_per_pixel = 5
+    s.settings.enable_bvh_tree = True
+    s.background = rt.GradientBackground([1.0, 1.0, 1.0], [0.5, 0.7, 1.0])
+    m = s.add_material(rt.Lambertian([0.7, 0.3, 0.3]))
+    g = s.add_material(rt.Metal([0.8, 0.8, 0.8], 0.1))
+    for c, r, mat in [([0.0, 0.0, -1.0], 0.5, m), ([0.0, -100.5, -1.0], 100.0, g), ([1.0, 0.0, -1.2], 0.4, g)][:n]:
+        s.add_object(rt.Sphere(c, r, mat))
+    return s
+
+
 @pytest.mark.parametrize("builder,w,h", [(lambda: house_scene(2), 160, 90), (lambda: simple_scene(4), 128, 128),
                                          (lambda: monkey_scene(3, material=rt.Dielectric(1.5)), 128, 72),
                                          (lambda: benchmark_scene(4, enable_bvh_tree=True), 128, 72),
-                                         (lambda: _fog_scene(True, two_volumes=True), 96, 64)])
+                                         (lambda: _fog_scene(True, two_volumes=True), 96, 64),
+                                         (lambda: _tiny_tree_scene(0), 40, 24), (lambda: _tiny_tree_scene(1), 40, 24),
+                                         (lambda: _tiny_tree_scene(2), 40, 24), (lambda: _tiny_tree_scene(3), 40, 24)])
 def test_tree_kernels_agree_bit_for_bit(builder, w, h):
     """Option tree_kernel: the wave-synchronous walk (k_render) and the resumable per-lane walk (k_render_bvh) execute
     the same operations per lane in the same order, so their frames must be identical to the last bit -- and equal the
