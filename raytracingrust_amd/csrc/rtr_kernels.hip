@@ -737,6 +737,23 @@ RTR_DEV V3 background(const RenderParams &p, const Ray &r) {
     return mk(texel.x, texel.y, texel.z);
 }
 
+// attenuation * (attenuation * (... * terminal)) (render.rs:52), then f32::clamp(0, clamp_indirect) with NaN staying
+// NaN (render.rs:95-97): the radiance one finished sample adds to its pixel
+RTR_DEV V3 sample_radiance(const RenderParams &p, const uint32_t *lds_mats, const uint32_t *chain, uint32_t lane, uint32_t &nchain, V3 term) {
+    while (nchain > 0u) {
+        nchain--;
+        term = mul(material_rgb(p, lds_mats, chain[nchain * 64u + lane]), term);
+    }
+    const float hi = p.clamp_indirect;
+    if (term.x < 0.0f) term.x = 0.0f;
+    if (term.x > hi) term.x = hi;
+    if (term.y < 0.0f) term.y = 0.0f;
+    if (term.y > hi) term.y = hi;
+    if (term.z < 0.0f) term.z = 0.0f;
+    if (term.z > hi) term.z = hi;
+    return term;
+}
+
 // The part of trace_ray (render.rs:38-58) after world.hit: background on a miss, else the material's scatter.
 // Returns `done` (the path ended: `term` is its terminal radiance) or false with the next segment in `ray`.
 RTR_DEV bool shade_segment(const RenderParams &p, bool was_hit, const Hit &h, Ray &ray, Rng &rng, const uint32_t *lds_mats,
@@ -950,20 +967,7 @@ __global__ __launch_bounds__(64, RTR_X_WAVES_PER_EU) void k_render(const RenderP
         done = shade_segment(p, was_hit, h, ray, rng, lds_mats, chain, lane, nchain, depth, term);
         RTR_STAMP(1)
         if (done) {
-            // attenuation * (attenuation * (... * terminal)), render.rs:52
-            while (nchain > 0u) {
-                nchain--;
-                term = mul(material_rgb(p, lds_mats, chain[nchain * 64u + lane]), term);
-            }
-            // f32::clamp(0, clamp_indirect), NaN stays NaN (render.rs:95-97)
-            const float hi = p.clamp_indirect;
-            if (term.x < 0.0f) term.x = 0.0f;
-            if (term.x > hi) term.x = hi;
-            if (term.y < 0.0f) term.y = 0.0f;
-            if (term.y > hi) term.y = hi;
-            if (term.z < 0.0f) term.z = 0.0f;
-            if (term.z > hi) term.z = hi;
-            acc = add(acc, term); // render.rs:99
+            acc = add(acc, sample_radiance(p, lds_mats, chain, lane, nchain, term)); // render.rs:99
             s++;
             if (s < spp) start_sample(s);
         }
@@ -1186,18 +1190,7 @@ __global__ __launch_bounds__(64, RTR_X_BVH_WAVES) void k_render_bvh(const Render
             V3 term;
             const bool done = shade_segment(p, was_hit, h, ray, rng, lds_mats, chain, lane, nchain, depth, term);
             if (done) {
-                while (nchain > 0u) { // render.rs:52
-                    nchain--;
-                    term = mul(material_rgb(p, lds_mats, chain[nchain * 64u + lane]), term);
-                }
-                const float hi = p.clamp_indirect; // render.rs:95-97
-                if (term.x < 0.0f) term.x = 0.0f;
-                if (term.x > hi) term.x = hi;
-                if (term.y < 0.0f) term.y = 0.0f;
-                if (term.y > hi) term.y = hi;
-                if (term.z < 0.0f) term.z = 0.0f;
-                if (term.z > hi) term.z = hi;
-                acc = add(acc, term);
+                acc = add(acc, sample_radiance(p, lds_mats, chain, lane, nchain, term)); // render.rs:99
                 s++;
                 if (s < spp) start_sample(s);
                 else alive = false;
