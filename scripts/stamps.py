@@ -24,7 +24,8 @@ for _ in range(5):
 r.render(W, H, seed=1)
 ring = [int(v) for v in r.segment_counts(64)]
 st = r.stats()
-names = ["loop top/regen tail", "after done block", "ball rejection loop", "material fetch + scatter", "world.hit"]
+# (shade_segment is one section since it became a function; the ball-rejection stamp inside it went away: always 0)
+names = ["loop top/regen tail", "after done block", "(unused)", "shade_segment: material fetch, sampler, scatter", "world.hit"]
 tot = sum(ring[:5])
 print(f"{cfg} {W}x{H}x{spp}: segments {ring[5]} kernel_ms {st.kernel_ms:.3f} (stamped build; read the shares, not the time)")
 for n, v in zip(names, ring[:5]):
