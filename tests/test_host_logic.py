@@ -257,3 +257,25 @@ def test_scene_json_writer_covers_every_type_and_refuses_meshes(tmp_path):
     s.add_object(rt.Mesh([[0, 0, 0], [1, 0, 0], [0, 1, 0]], [[0, 0, 1]] * 3, [0, 1, 2], lam))
     with pytest.raises(ValueError):
         s.to_dict()
+
+
+def test_options_are_validated_without_a_device():
+    """rtr_set_option works on a host-only context: known names take their documented values, anything else is
+    RTR_ERR_INVALID_ARGUMENT; tree options change the flattened tree, kernel options do not."""
+    with rt.Renderer(-1) as r:
+        for name, good, bad in [("mesh_tree", ["reference", "sah"], "octree"), ("scene_tree", ["sah", "reference"], ""),
+                                ("leaf_pairs", ["off", "on"], "maybe"), ("tree_kernel", ["wave", "resumable", "auto"], "fast")]:
+            for v in good:
+                r.set_option(name, v)
+            with pytest.raises(rt.RtrError):
+                r.set_option(name, bad)
+        with pytest.raises(rt.RtrError):
+            r.set_option("no_such_option", "1")
+        s = simple_scene(1)
+        r.upload_scene(s)
+        base = r.scene_info()
+        r.set_option("leaf_pairs", "off")
+        r.upload_scene(s)
+        off = r.scene_info()
+        assert (off.n_nodes, off.n_leaves, off.tree_height) == (base.n_nodes, base.n_leaves, base.tree_height)
+        assert off.device_bytes >= base.device_bytes  # unfolded pairs are node records again
