@@ -145,8 +145,9 @@ int launch_frame(rtr_context *ctx, const rtr_camera *camera, const rtr_settings 
     else { p.world = rtr::WORLD_LINEAR_GENERIC; p.stack_cap = fs.mesh_stack_depth + 1u; }
     p.n_objects = fs.n_objects;
     p.has_volumes = fs.has_volumes ? 1u : 0u;
-    // the resumable walk pays for its state machine once walks are long and uneven: scenes with meshes (measured:
-    // +35 % on house.obj, +8 % on monkey.obj; -5 ... -10 % on the 102- and 5-sphere trees, reference or SAH built)
+    // "auto": the resumable walk (k_render_bvh) for scenes with meshes.  Measured against the wave-synchronous
+    // k_render<BVH>: +45 % on house.obj, +10 % on monkey.obj; on sphere-only trees equal within 2 % (reference trees)
+    // or 7 % behind (SAH trees), so those keep k_render.
     p.resumable_walk = (ctx->tree_kernel == 1 || (ctx->tree_kernel == 0 && fs.n_triangles > 0u)) ? 1u : 0u;
     p.has_meshes = fs.n_triangles > 0u ? 1u : 0u;
     p.root_ref = fs.root_ref;
