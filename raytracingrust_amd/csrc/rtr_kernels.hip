@@ -1015,15 +1015,15 @@ __global__ __launch_bounds__(64, RTR_X_WAVES_PER_EU) void k_render(const RenderP
 // ---- WORLD_BVH with a resumable walk -------------------------------------------------------------------------------
 // In k_render a wave leaves world.hit only when its slowest lane has finished its walk: rays that need 10 trips wait
 // for rays that need 60 (C4: 19 % of VALU lane-cycles active).  Here the walk is a per-lane state machine inside the
-// main loop: lanes take traversal trips until no more than `1/RTR_TREE_QUORUM_DEN` of the wave's live lanes are still
+// main loop: lanes take traversal trips until no more than 5/8 (RTR_TREE_QUORUM_*) of the wave's live lanes are still
 // walking, then the lanes whose walk has ended shade, scatter or regenerate together and rejoin with a fresh walk, while
 // the late walkers simply keep their state.  Every lane executes exactly the operations it executes in k_render, in the
 // same order (its random stream included), so the frame is bit-identical; only the interleaving between lanes changes.
 #ifndef RTR_TREE_QUORUM_NUM
-#define RTR_TREE_QUORUM_NUM 1
+#define RTR_TREE_QUORUM_NUM 5
 #endif
 #ifndef RTR_TREE_QUORUM_DEN
-#define RTR_TREE_QUORUM_DEN 2
+#define RTR_TREE_QUORUM_DEN 8
 #endif
 #ifndef RTR_X_WALK_UNROLL
 #define RTR_X_WALK_UNROLL 4
