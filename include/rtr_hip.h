@@ -206,6 +206,11 @@ int rtr_abi_version(void);
  *                 finished.  "resumable": the walk is a per-lane state machine inside the main loop, so lanes that are
  *                 done shade and start their next ray while the others keep walking.  Same per-lane operations in the
  *                 same order: bit-identical frames.  "auto" takes "resumable" for scenes that hold meshes. */
+/*   "sample_chunks" = "auto" (default) | "1" .. "4096" (applied at the next render): pieces every pixel's sample range
+ *                 is cut into inside one launch.  Each piece continues the running sums of the one before it in the
+ *                 same order, so the frame is bit-identical for every value; more pieces shorten the tail of a launch
+ *                 that has few tiles per resident wave (1080p: -9 % with 4) and cost a workgroup prologue each.
+ *                 Launches of one context that use chunks share scratch buffers: issue them on one stream. */
 int rtr_set_option(rtr_context *ctx, const char *name, const char *value);
 /* Lower + build + flatten + copy to HBM.  Replaces any previous scene of the context. */
 int rtr_upload_scene(rtr_context *ctx, const rtr_scene_desc *scene);

@@ -113,6 +113,10 @@ struct RenderParams {
     uint32_t sky_w, sky_h;
     // tile sharding
     uint32_t tiles_x, tiles_total, shard, n_shards;
+    uint32_t tiles_launch;  // tiles this launch renders (shard, shard + n_shards, ...): grid = tiles_launch * chunks
+    uint32_t chunks;        // pieces every pixel's sample range is cut into (>= 1), chunk-major in blockIdx
+    float *carry_rgba;      // float4 running sums handed from chunk to chunk (chunks > 1)
+    uint32_t *chunk_flags;  // per launch-local tile: chunks completed; [tiles_launch] = timeout flag (chunks > 1)
     // outputs
     float *sum_rgba;             // float4 per pixel (sharded path) or nullptr
     uint8_t *rgba8;              // fused path or nullptr

@@ -847,6 +847,30 @@ RTR_DEV bool shade_segment(const RenderParams &p, bool was_hit, const Hit &h, Ra
     return done;
 }
 
+// Sample chunks.  A launch may cut every pixel's sample range into p.chunks consecutive pieces, one workgroup per
+// (chunk, tile), chunk-major in blockIdx: the tail of the launch then consists of short pieces instead of whole tiles
+// (at 1080p the frame is only ~4 waves' worth of tiles per wave slot, and 11 % of the time was spent with the chip
+// draining).  Chunk c of a tile starts from the running sums chunk c-1 left in p.carry_rgba and adds its samples
+// in the same order, so every pixel sees exactly the additions of the unchunked loop: bit-identical.  The hand-over is
+// a per-tile counter: written with release, read with acquire (agent scope).  A workgroup of chunk c is dispatched a
+// whole chunk's worth of workgroups after its predecessor, so the wait is normally over before it starts; it is
+// bounded all the same, and a timeout is reported through the word behind the last tile's counter.
+RTR_DEV void chunk_wait(const RenderParams &p, uint32_t tidx, uint32_t chunk) {
+    uint32_t spins = 0;
+    while (__hip_atomic_load(p.chunk_flags + tidx, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < chunk) {
+        __builtin_amdgcn_s_sleep(16);
+        if (++spins > (1u << 24)) { // ~seconds: the predecessor cannot be that late; give up rather than hang the GPU
+            __hip_atomic_store(p.chunk_flags + p.tiles_launch, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+        }
+    }
+}
+RTR_DEV void chunk_publish(const RenderParams &p, uint32_t tidx, uint32_t chunk, uint32_t lane) {
+    __threadfence(); // the wave's carry stores are visible device-wide before the counter moves
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) __hip_atomic_store(p.chunk_flags + tidx, chunk + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // One wave = one 8x8 tile.  LDS (dynamic, 16-byte aligned pieces):
 //   [chain: max_depth x 64 u32][stack refs: cap x 64][stack t: cap x 64][spheres: NS x 8][materials: lds_mats x 8]
 #ifndef RTR_X_WAVES_PER_EU
@@ -860,7 +884,8 @@ __attribute__((amdgpu_num_sgpr(96)))
 __global__ __launch_bounds__(64, RTR_X_WAVES_PER_EU) void k_render(const RenderParams p) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const uint32_t lane = threadIdx.x;
-    const uint32_t tile = blockIdx.x * p.n_shards + p.shard;
+    const uint32_t chunk = blockIdx.x / p.tiles_launch, tidx = blockIdx.x - chunk * p.tiles_launch;
+    const uint32_t tile = tidx * p.n_shards + p.shard;
     if (tile >= p.tiles_total) return;
     uint32_t *chain = lds;
     uint32_t *stk_ref = lds + p.max_depth * 64u;
@@ -908,8 +933,17 @@ __global__ __launch_bounds__(64, RTR_X_WAVES_PER_EU) void k_render(const RenderP
     uint32_t nseg = 0;
     // samples [sample_begin, sample_begin + sample_count) of this pixel; the random stream is keyed by the
     // absolute sample index, so a frame split by samples over several launches / GPUs draws the same numbers
-    const uint32_t spp = (inside && p.max_depth > 0u) ? p.sample_begin + p.sample_count : 0u;
-    uint32_t s = p.sample_begin, depth = 0, nchain = 0;
+    const uint32_t s_first = p.sample_begin + (uint32_t)((uint64_t)p.sample_count * chunk / p.chunks);
+    const uint32_t s_last = p.sample_begin + (uint32_t)((uint64_t)p.sample_count * (chunk + 1u) / p.chunks);
+    const uint32_t spp = (inside && p.max_depth > 0u) ? s_last : s_first;
+    uint32_t s = s_first, depth = 0, nchain = 0;
+    if (chunk > 0u) { // continue from the sums the previous chunk of this tile left behind
+        chunk_wait(p, tidx, chunk);
+        if (inside) {
+            const float4 c = reinterpret_cast<const float4 *>(p.carry_rgba)[pixel];
+            acc = mk(c.x, c.y, c.z);
+        }
+    }
     Ray ray;
     ray.o = cam_o; ray.d = cam_o;
 
@@ -978,7 +1012,10 @@ __global__ __launch_bounds__(64, RTR_X_WAVES_PER_EU) void k_render(const RenderP
         for (int k = 0; k < 5; k++) atomicAdd(p.counter - 1 - k, st_acc[k]);
 #endif
 
-    if (inside) {
+    if (chunk + 1u < p.chunks) {
+        if (inside) reinterpret_cast<float4 *>(p.carry_rgba)[pixel] = make_float4(acc.x, acc.y, acc.z, 0.0f);
+        chunk_publish(p, tidx, chunk, lane);
+    } else if (inside) {
         if (p.sum_rgba) {
             reinterpret_cast<float4 *>(p.sum_rgba)[pixel] = make_float4(acc.x, acc.y, acc.z, 0.0f);
         }
@@ -1037,7 +1074,8 @@ __attribute__((amdgpu_num_sgpr(96)))
 __global__ __launch_bounds__(64, RTR_X_BVH_WAVES) void k_render_bvh(const RenderParams p) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const uint32_t lane = threadIdx.x;
-    const uint32_t tile = blockIdx.x * p.n_shards + p.shard;
+    const uint32_t chunk = blockIdx.x / p.tiles_launch, tidx = blockIdx.x - chunk * p.tiles_launch;
+    const uint32_t tile = tidx * p.n_shards + p.shard;
     if (tile >= p.tiles_total) return;
     uint32_t *chain = lds;
     uint32_t *stk_ref = lds + p.max_depth * 64u;
@@ -1062,8 +1100,17 @@ __global__ __launch_bounds__(64, RTR_X_BVH_WAVES) void k_render_bvh(const Render
 
     V3 acc = mk(0.0f, 0.0f, 0.0f);
     uint32_t nseg = 0;
-    const uint32_t spp = (inside && p.max_depth > 0u) ? p.sample_begin + p.sample_count : 0u;
-    uint32_t s = p.sample_begin, depth = 0, nchain = 0;
+    const uint32_t s_first = p.sample_begin + (uint32_t)((uint64_t)p.sample_count * chunk / p.chunks);
+    const uint32_t s_last = p.sample_begin + (uint32_t)((uint64_t)p.sample_count * (chunk + 1u) / p.chunks);
+    const uint32_t spp = (inside && p.max_depth > 0u) ? s_last : s_first;
+    uint32_t s = s_first, depth = 0, nchain = 0;
+    if (chunk > 0u) { // continue from the sums the previous chunk of this tile left behind
+        chunk_wait(p, tidx, chunk);
+        if (inside) {
+            const float4 c = reinterpret_cast<const float4 *>(p.carry_rgba)[pixel];
+            acc = mk(c.x, c.y, c.z);
+        }
+    }
     Ray ray;
     ray.o = cam_o; ray.d = cam_o;
     const SharedDiv div_w = shared_div_prepare(p.width_m1), div_h = shared_div_prepare(p.height_m1);
@@ -1208,7 +1255,10 @@ __global__ __launch_bounds__(64, RTR_X_BVH_WAVES) void k_render_bvh(const Render
         }
     }
 
-    if (inside) {
+    if (chunk + 1u < p.chunks) {
+        if (inside) reinterpret_cast<float4 *>(p.carry_rgba)[pixel] = make_float4(acc.x, acc.y, acc.z, 0.0f);
+        chunk_publish(p, tidx, chunk, lane);
+    } else if (inside) {
         if (p.sum_rgba) reinterpret_cast<float4 *>(p.sum_rgba)[pixel] = make_float4(acc.x, acc.y, acc.z, 0.0f);
         if (p.rgba8 || p.mean_rgb) { // render.rs:103-110
             const float n = (float)p.spp;
@@ -1335,8 +1385,27 @@ hipError_t launch_resolve(const float *sum_rgba, uint32_t spp, uint32_t n_pixels
     return hipGetLastError();
 }
 
+static const void *render_kernel(const RenderParams &p);
+
+// 64-thread workgroups of the kernel launch_render would take that the current device keeps resident
+uint32_t render_resident_waves(const RenderParams &p, uint32_t lds_bytes) {
+    int per_cu = 0, dev = 0, cus = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, render_kernel(p), 64, lds_bytes) != hipSuccess || per_cu <= 0) per_cu = 16;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    return (uint32_t)per_cu * (uint32_t)cus;
+}
+
 hipError_t render_kernel_attributes(const RenderParams &p, int *vgprs, int *static_lds) {
     hipFuncAttributes attr;
+    const void *fn = render_kernel(p);
+    hipError_t e = hipFuncGetAttributes(&attr, fn);
+    if (e != hipSuccess) return e;
+    *vgprs = attr.numRegs;
+    *static_lds = (int)attr.sharedSizeBytes;
+    return hipSuccess;
+}
+
+static const void *render_kernel(const RenderParams &p) {
     const void *fn;
     if (p.world == WORLD_BVH && p.resumable_walk)
         fn = p.has_volumes ? (p.has_meshes ? reinterpret_cast<const void *>(k_render_bvh<true, true>) : reinterpret_cast<const void *>(k_render_bvh<true, false>))
@@ -1362,9 +1431,7 @@ hipError_t render_kernel_attributes(const RenderParams &p, int *vgprs, int *stat
         default: fn = reinterpret_cast<const void *>(k_render<WORLD_LINEAR_SPHERES, 0, false, false>); break;
         }
     }
-    hipError_t e = hipFuncGetAttributes(&attr, fn);
-    if (e == hipSuccess) { *vgprs = attr.numRegs; *static_lds = (int)attr.sharedSizeBytes; }
-    return e;
+    return fn;
 }
 
 } // namespace rtr

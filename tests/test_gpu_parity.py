@@ -544,3 +544,53 @@ def test_tree_kernels_agree_bit_for_bit(builder, w, h):
     assert o_st.segments == frames["wave"][2]
     c = compare(frames["resumable"][1].view(np.float32), frames["resumable"][0], o_mean, o_rgba)
     assert max(c["rel_l2"]) <= TOL and c["max_u8_delta"] <= 1, c
+
+
+@pytest.mark.parametrize("builder,w,h", [(lambda: benchmark_scene(13), 97, 61), (lambda: house_scene(5), 96, 54),
+                                         (lambda: simple_scene(7), 64, 64), (lambda: monkey_scene(6, bvh=False), 64, 36),
+                                         (lambda: _fog_scene(True, spp=9, two_volumes=True), 48, 32)])
+def test_sample_chunks_do_not_change_a_bit(builder, w, h):
+    """Option sample_chunks: one launch renders every pixel's samples in consecutive pieces (chunk-major workgroups,
+    running sums handed over through memory).  Same additions in the same order: the frame and the segment count are
+    identical for every chunk count, including counts that do not divide spp and more chunks than samples."""
+    scene = builder()
+    frames = []
+    with rt.Renderer(0) as r:
+        r.upload_scene(scene)
+        for chunks in ("1", "auto", "2", "3", "4", "7", "64"):
+            r.set_option("sample_chunks", chunks)
+            rgba, mean = r.render(w, h, seed=19, want_rgba8=True, want_mean=True)
+            frames.append((rgba, mean.view(np.uint32).copy(), r.stats().segments))
+        for bad in ("0", "4097", "many", ""):
+            with pytest.raises(rt.RtrError):
+                r.set_option("sample_chunks", bad)
+    for rgba, mean_bits, seg in frames[1:]:
+        assert seg == frames[0][2]
+        assert np.array_equal(rgba, frames[0][0]) and np.array_equal(mean_bits, frames[0][1])
+    o_rgba, o_mean, o_st = pyoracle.OracleScene(scene, trig_mode=pyoracle.TRIG_POLY).render(w, h, 19, threads=0)
+    assert o_st.segments == frames[0][2]
+
+
+def test_sample_chunks_in_the_sharded_paths(gpu_renderer):
+    """Chunks inside the sample-sharded and tile-sharded launches (what each rank of the multi-GPU path runs): the
+    float4 sums must equal the unchunked ones bit for bit."""
+    import torch
+
+    r = gpu_renderer
+    scene = benchmark_scene(24)
+    w, h = 120, 72
+    r.upload_scene(scene)
+    dev = torch.device("cuda", 0)
+    out = {}
+    try:
+        for chunks in ("1", "3"):
+            r.set_option("sample_chunks", chunks)
+            a = torch.zeros((h, w, 4), dtype=torch.float32, device=dev)
+            b = torch.zeros((h, w, 4), dtype=torch.float32, device=dev)
+            r.render_samples_device(w, h, 5, 6, 11, a.data_ptr(), scene=scene)   # samples [6, 17)
+            r.render_tiles_device(w, h, 5, 1, 3, b.data_ptr(), scene=scene)      # shard 1 of 3
+            torch.cuda.synchronize()
+            out[chunks] = (a.cpu().numpy().view(np.uint32).copy(), b.cpu().numpy().view(np.uint32).copy())
+    finally:
+        r.set_option("sample_chunks", "auto")
+    assert np.array_equal(out["1"][0], out["3"][0]) and np.array_equal(out["1"][1], out["3"][1])
