@@ -252,8 +252,9 @@ def main():
                 "valu_issue": valu_issue(args, world, my_kernel_ms),
                 "note": "algorithmic bytes are SURVEY 8(d)'s streaming-wavefront model (48 B of path state in and out "
                         "per segment + geometry records); this kernel keeps path state in registers and the scene in "
-                        "SGPRs/LDS/L1, so measured HBM traffic is ~the framebuffer and frac can exceed 1: the kernel "
-                        "is VALU-issue bound (DESIGN.md section 5)",
+                        "SGPRs/LDS/L1, so measured HBM traffic is the framebuffer plus the running sums handed between "
+                        "sample chunks (~0.17 GB per launch) and frac can exceed 1: the kernel is VALU-issue bound "
+                        "(DESIGN.md section 5)",
             },
         }
         if not args.no_cpu_baseline and world == 1:
