@@ -232,6 +232,7 @@ int launch_frame(rtr_context *ctx, const rtr_camera *camera, const rtr_settings 
         want = std::max(1u, std::min(want, std::max(1u, sample_count)));
         if ((uint64_t)grid * want > 0x7FFFFFFFull) want = 1u;
         p.chunks = want;
+        p.chunk_taper = p.world == rtr::WORLD_LINEAR_SPHERES ? 6u : 0u; // see chunk_boundary
     }
     ctx->last_chunks = p.chunks; ctx->last_tiles_launch = grid;
     if (p.chunks > 1u) {

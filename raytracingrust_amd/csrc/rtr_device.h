@@ -115,6 +115,7 @@ struct RenderParams {
     uint32_t tiles_x, tiles_total, shard, n_shards;
     uint32_t tiles_launch;  // tiles this launch renders (shard, shard + n_shards, ...): grid = tiles_launch * chunks
     uint32_t chunks;        // pieces every pixel's sample range is cut into (>= 1), chunk-major in blockIdx
+    uint32_t chunk_taper;   // 0: equal pieces; k in 1..7: lengths fall linearly from (8+k)/8 to (8-k)/8 of the mean
     float *carry_rgba;      // float4 running sums handed from chunk to chunk (chunks > 1)
     uint32_t *chunk_flags;  // per launch-local tile: chunks completed; [tiles_launch] = timeout flag (chunks > 1)
     // outputs

@@ -855,6 +855,19 @@ RTR_DEV bool shade_segment(const RenderParams &p, bool was_hit, const Hit &h, Ra
 // a per-tile counter: written with release, read with acquire (agent scope).  A workgroup of chunk c is dispatched a
 // whole chunk's worth of workgroups after its predecessor, so the wait is normally over before it starts; it is
 // bounded all the same, and a timeout is reported through the word behind the last tile's counter.
+// First sample (relative) of chunk c of n.  With taper k (0..7) the chunk lengths fall linearly from (8+k)/8 of the mean
+// to (8-k)/8: what is left running when the launch has no more workgroups to start are pieces of the LAST chunk, so that
+// one should be the smallest.  1080p headline: equal chunks 16.85 ms, k = 2: 16.6, 4: 16.4, 6: 16.2, 7: 16.0-16.1
+// (halving chunks: 16.9); the tree kernels prefer equal chunks (k = 6: C1 -4 %, C3 -2 %, C4 -6 %), so the launcher
+// sets k = 6 for the sphere world only.
+RTR_DEV uint32_t chunk_boundary(uint32_t count, uint32_t c, uint32_t n, uint32_t taper) {
+    if (taper == 0u || n < 2u) return (uint32_t)((uint64_t)count * c / n);
+    // cumulative weight of chunks 0..c-1 with weight_i = 8 + k - 2k*i/(n-1), 8n in total
+    const uint64_t k = taper;
+    const uint64_t num = (uint64_t)c * (8u + k) * (n - 1u) - k * (uint64_t)c * (c - 1u);
+    return (uint32_t)((uint64_t)count * num / (8ull * n * (n - 1u)));
+}
+
 RTR_DEV void chunk_wait(const RenderParams &p, uint32_t tidx, uint32_t chunk) {
     uint32_t spins = 0;
     while (__hip_atomic_load(p.chunk_flags + tidx, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < chunk) {
@@ -933,8 +946,8 @@ __global__ __launch_bounds__(64, RTR_X_WAVES_PER_EU) void k_render(const RenderP
     uint32_t nseg = 0;
     // samples [sample_begin, sample_begin + sample_count) of this pixel; the random stream is keyed by the
     // absolute sample index, so a frame split by samples over several launches / GPUs draws the same numbers
-    const uint32_t s_first = p.sample_begin + (uint32_t)((uint64_t)p.sample_count * chunk / p.chunks);
-    const uint32_t s_last = p.sample_begin + (uint32_t)((uint64_t)p.sample_count * (chunk + 1u) / p.chunks);
+    const uint32_t s_first = p.sample_begin + chunk_boundary(p.sample_count, chunk, p.chunks, p.chunk_taper);
+    const uint32_t s_last = p.sample_begin + chunk_boundary(p.sample_count, chunk + 1u, p.chunks, p.chunk_taper);
     const uint32_t spp = (inside && p.max_depth > 0u) ? s_last : s_first;
     uint32_t s = s_first, depth = 0, nchain = 0;
     if (chunk > 0u) { // continue from the sums the previous chunk of this tile left behind
@@ -1100,8 +1113,8 @@ __global__ __launch_bounds__(64, RTR_X_BVH_WAVES) void k_render_bvh(const Render
 
     V3 acc = mk(0.0f, 0.0f, 0.0f);
     uint32_t nseg = 0;
-    const uint32_t s_first = p.sample_begin + (uint32_t)((uint64_t)p.sample_count * chunk / p.chunks);
-    const uint32_t s_last = p.sample_begin + (uint32_t)((uint64_t)p.sample_count * (chunk + 1u) / p.chunks);
+    const uint32_t s_first = p.sample_begin + chunk_boundary(p.sample_count, chunk, p.chunks, p.chunk_taper);
+    const uint32_t s_last = p.sample_begin + chunk_boundary(p.sample_count, chunk + 1u, p.chunks, p.chunk_taper);
     const uint32_t spp = (inside && p.max_depth > 0u) ? s_last : s_first;
     uint32_t s = s_first, depth = 0, nchain = 0;
     if (chunk > 0u) { // continue from the sums the previous chunk of this tile left behind
