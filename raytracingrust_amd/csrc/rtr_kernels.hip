@@ -872,7 +872,7 @@ RTR_DEV void chunk_wait(const RenderParams &p, uint32_t tidx, uint32_t chunk) {
     uint32_t spins = 0;
     while (__hip_atomic_load(p.chunk_flags + tidx, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < chunk) {
         __builtin_amdgcn_s_sleep(16);
-        if (++spins > (1u << 24)) { // ~seconds: the predecessor cannot be that late; give up rather than hang the GPU
+        if (++spins > (1u << 28)) { // ~2 minutes: far beyond any predecessor's lifetime; give up rather than hang the GPU
             __hip_atomic_store(p.chunk_flags + p.tiles_launch, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             break;
         }
