@@ -201,11 +201,17 @@ int rtr_abi_version(void);
  *                 ranks is stored inside its parent (same box test, same two leaf tests in the same order, one traversal
  *                 step fewer).  Decisions are identical either way -- frames are bit-identical; "off" exists for A/B
  *                 measurements.
- *   "tree_kernel" = "auto" (default) | "resumable" | "wave" (applied at the next render): which kernel walks the
- *                 tree when enable_bvh_tree is set.  "wave": a wave returns from world.hit when its slowest lane has
- *                 finished.  "resumable": the walk is a per-lane state machine inside the main loop, so lanes that are
- *                 done shade and start their next ray while the others keep walking.  Same per-lane operations in the
- *                 same order: bit-identical frames.  "auto" takes "resumable" for scenes that hold meshes. */
+ *   "tree_kernel" = "auto" (default) | "samples" | "resumable" | "wave" (applied at the next render): which kernel
+ *                 walks the tree when enable_bvh_tree is set.  "wave": a wave returns from world.hit when its slowest
+ *                 lane has finished.  "resumable": the walk is a per-lane state machine inside the main loop, so lanes
+ *                 that are done shade and start their next ray while the others keep walking.  "samples": the same
+ *                 walk, but a lane takes (sample, pixel) pairs of its tile instead of owning one pixel; each sample's
+ *                 clamped radiance is written to device memory (16 bytes per sample, in batches of at most 16 GiB)
+ *                 and a second kernel adds every pixel's samples in index order.  Every lane-level operation and
+ *                 every addition is the same in all three: bit-identical frames.  "auto": scenes with meshes take
+ *                 "samples" (inside tile-sharded launches, where it does not apply: "resumable"), others "wave". */
+/*   "samples_batch" = "0" (default: as many samples as 16 GiB hold) | N: samples per batch of the "samples" kernel's
+ *                 radiance buffer; a pixel's running sum is carried from batch to batch, so any N gives the same frame. */
 /*   "sample_chunks" = "auto" (default) | "1" .. "4096" (applied at the next render): pieces every pixel's sample range
  *                 is cut into inside one launch.  Each piece continues the running sums of the one before it in the
  *                 same order, so the frame is bit-identical for every value; more pieces shorten the tail of a launch

@@ -97,6 +97,7 @@ struct RenderParams {
     uint32_t sphere_regs;   // linear sphere world: spheres held in scalar registers (0 = generic loop)
     uint32_t lds_materials; // number of material records staged in LDS (0 = read from HBM/L1)
     uint32_t has_meshes;    // the scene holds triangles: tree kernels instantiated with the unconditional slab tests
+    uint32_t sample_parallel; // WORLD_BVH: k_render_bvh_sp + k_sum_samples
     uint32_t resumable_walk; // WORLD_BVH: k_render_bvh (per-lane walk state machine) instead of k_render
     uint32_t has_volumes;   // the scene holds Volume objects: kernels instantiated with the visit-order rules
     const DevNode *nodes;
@@ -117,6 +118,7 @@ struct RenderParams {
     uint32_t chunks;        // pieces every pixel's sample range is cut into (>= 1), chunk-major in blockIdx
     uint32_t chunk_taper;   // 0: equal pieces; k in 1..7: lengths fall linearly from (8+k)/8 to (8-k)/8 of the mean
     float *carry_rgba;      // float4 running sums handed from chunk to chunk (chunks > 1)
+    float *samples;         // k_render_bvh_sp: float4 [sample - sample_begin][pixel], one clamped radiance per sample
     uint32_t *chunk_flags;  // per launch-local tile: chunks completed; [tiles_launch] = timeout flag (chunks > 1)
     // outputs
     float *sum_rgba;             // float4 per pixel (sharded path) or nullptr

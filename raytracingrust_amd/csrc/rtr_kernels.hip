@@ -1293,6 +1293,263 @@ __global__ __launch_bounds__(64, RTR_X_BVH_WAVES) void k_render_bvh(const Render
     if (lane == 0 && total) atomicAdd(p.counter, total);
 }
 
+// ---- WORLD_BVH, samples instead of pixels ------------------------------------------------------------------------
+// k_render_bvh ties a lane to one pixel because the pixel's samples are SUMMED in order -- but they need not be RENDERED
+// in order.  Here a workgroup owns (tile, sample range) and its lanes take (sample, pixel) pairs from a wave-level
+// counter as they finish; each sample's clamped radiance is written to p.samples[sample][pixel], and k_sum_samples adds
+// a pixel's samples in index order afterwards (the same additions as calculate_pixel's loop).  No lane waits for its
+// tile's slowest pixel, and sample ranges need no hand-over between workgroups.
+template <bool VOL, bool MESH>
+__attribute__((amdgpu_num_sgpr(96)))
+__global__ __launch_bounds__(64, RTR_X_BVH_WAVES) void k_render_bvh_sp(const RenderParams p) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t chunk = blockIdx.x / p.tiles_launch, tidx = blockIdx.x - chunk * p.tiles_launch;
+    const uint32_t tile = tidx * p.n_shards + p.shard;
+    if (tile >= p.tiles_total) return;
+    uint32_t *chain = lds;
+    uint32_t *stk_ref = lds + p.max_depth * 64u;
+    float *stk_t = reinterpret_cast<float *>(stk_ref + p.stack_cap * 64u);
+    uint32_t *lds_mat_base = reinterpret_cast<uint32_t *>(stk_t + p.stack_cap * 64u);
+    const uint32_t *lds_mats = p.lds_materials ? lds_mat_base : nullptr;
+    if (p.lds_materials)
+        for (uint32_t i = lane; i < p.lds_materials * 8u; i += 64u) lds_mat_base[i] = reinterpret_cast<const uint32_t *>(p.materials)[i];
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+
+    const uint32_t tx = tile % p.tiles_x, ty = tile / p.tiles_x;
+    const V3 cam_o = ld3(p.cam_origin), cam_h = ld3(p.cam_horizontal), cam_v = ld3(p.cam_vertical), cam_llc = ld3(p.cam_llc);
+    // the lane's current work item: one sample of one pixel of the tile
+    uint32_t hp = 0;
+    float fx = 0.0f, fy = 0.0f;
+    uint64_t slot = 0; // where the sample's radiance goes: [sample - sample_begin][pixel]
+    Rng rng;
+    rng.inc = 1u; rng.state = 0u;
+    uint32_t nseg = 0;
+    const uint32_t s_first = p.sample_begin + chunk_boundary(p.sample_count, chunk, p.chunks, 0u);
+    const uint32_t s_last = p.sample_begin + chunk_boundary(p.sample_count, chunk + 1u, p.chunks, 0u);
+    const uint32_t n_items = 64u * (s_last - s_first); // (sample, pixel) pairs of this workgroup, sample-major
+    uint32_t next_item = 0;                            // wave-uniform
+    uint32_t depth = 0, nchain = 0;
+    Ray ray;
+    ray.o = cam_o; ray.d = cam_o;
+    const SharedDiv div_w = shared_div_prepare(p.width_m1), div_h = shared_div_prepare(p.height_m1);
+    const bool uv_fast = div_w.ok && div_h.ok;
+    auto start_sample = [&](uint32_t si) { // render.rs:80-90, camera.rs:19-24 (as in k_render)
+        rng.state = hash32(hp + si * 0x9E3779B9u);
+        float u = fx + rng_unit_inclusive(rng);
+        float v = fy + rng_unit_inclusive(rng);
+        if (uv_fast) {
+            u = shared_div(u, div_w.d, div_w.r1);
+            v = shared_div(v, div_h.d, div_h.r1);
+        } else {
+            u = u / p.width_m1;
+            v = v / p.height_m1;
+        }
+        ray.o = cam_o;
+        ray.d = sub(sub(add(cam_llc, scale(cam_h, u)), scale(cam_v, v)), cam_o);
+        depth = 0; nchain = 0;
+    };
+
+    // the walk's per-lane state (world_hit + traverse of k_render, unrolled into the loop below)
+    uint32_t cur = REF_NONE, sp = 0;
+    Best best;
+    best.leaf = REF_NONE; best.t = __builtin_inff(); best.u = 0.0f; best.v = 0.0f;
+    V3 inv = mk(0.0f, 0.0f, 0.0f);
+    float a = 0.0f;
+    bool walking = false;
+    auto begin_segment = [&]() { // the head of world_hit<WORLD_BVH>
+        nseg++;
+        a = dot(ray.d, ray.d);
+        inv = mk(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z);
+        best.leaf = REF_NONE; best.t = __builtin_inff(); best.u = 0.0f; best.v = 0.0f;
+        const uint32_t root = p.root_ref;
+        bool go = root != REF_NONE;
+        if (go && (root & (REF_LEAF | REF_PAIR)) != REF_LEAF) {
+            float e;
+            go = slab(p.root_box, p.root_box + 3, ray, inv, __builtin_inff(), e);
+        }
+        cur = root; sp = 0;
+        walking = go;
+    };
+    bool alive = false;
+    bool need = true; // the lane wants the workgroup's next (sample, pixel) pair
+    const uint64_t n_pixels = (uint64_t)p.width * p.height;
+    auto fetch_work = [&]() { // hand the next items to the lanes that ask, in lane order; wave-uniform control flow
+        while (__ballot(need) != 0ull) {
+            const uint64_t asking = __ballot(need);
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(asking >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)asking, 0u));
+            const uint32_t item = next_item + rank;
+            next_item += (uint32_t)__popcll(asking);
+            if (need) {
+                if (item >= n_items) {
+                    need = false; // nothing left: the lane retires
+                } else {
+                    const uint32_t pix = item & 63u, si = s_first + (item >> 6);
+                    const uint32_t x = tx * 8u + (pix & 7u), y = ty * 8u + (pix >> 3);
+                    if (x < p.width && y < p.height) { // else: off the ragged edge, ask again
+                        const uint32_t pixel = y * p.width + x; // render.rs:76-77
+                        fx = (float)x; fy = (float)y;
+                        hp = hash32(pixel ^ p.seed_lo);
+                        rng.inc = (hash32(hp + p.seed_hi) << 1) | 1u;
+                        slot = (uint64_t)(si - p.sample_begin) * n_pixels + pixel;
+                        need = false;
+                        alive = true;
+                        start_sample(si);
+                        begin_segment();
+                    }
+                }
+            }
+        }
+    };
+    fetch_work();
+
+    for (;;) {
+        const uint64_t alive_mask = __ballot(alive);
+        if (alive_mask == 0ull) break;
+        const uint32_t quorum = (uint32_t)__popcll(alive_mask) * RTR_TREE_QUORUM_NUM / RTR_TREE_QUORUM_DEN;
+        // ---- walk: one trip per iteration for every lane still walking ----
+        // (The trip is `traverse`'s loop body, repeated here on purpose: as one function shared by both callers it
+        // compiled 6 ... 18 % slower in either.)
+        while ((uint32_t)__popcll(__ballot(walking)) > quorum) {
+            // (Taking only the kind of step -- node or leaf -- that more walkers wait for was measured 0 ... -10 %:
+            // with both bodies in one trip their gathers overlap.)
+            // kWalkUnroll trips per quorum check: C3 +15 %, C4 +5 % over one (2, 3, 4, 6, 8 measured: flat from 3 on)
+#pragma unroll
+            for (uint32_t rep = 0; rep < kWalkUnroll; rep++)
+            if (walking) {
+                bool pop = false;
+                if (cur & REF_LEAF) {
+                    test_leaf<VOL>(p, cur & ~REF_PAIR, ray, a, best, rng);
+                    pop = !(cur & REF_PAIR);
+                    cur = (cur & ~REF_PAIR) + 1u;
+                } else {
+                    const float4 *nq = reinterpret_cast<const float4 *>(p.nodes + cur);
+                    float4 q0 = nq[0], q1 = nq[1], q2 = nq[2], q3 = nq[3];
+                    gather_fence(q0, q1, q2, q3);
+                    float lmin[3] = {q0.x, q0.y, q0.z}, lmax[3] = {q0.w, q1.x, q1.y};
+                    float rmin[3] = {q1.z, q1.w, q2.x}, rmax[3] = {q2.y, q2.z, q2.w};
+                    uint32_t l = __float_as_uint(q3.x), rr = __float_as_uint(q3.y);
+                    const uint32_t flags = __float_as_uint(q3.z);
+                    const bool lvol = VOL && (flags & NODE_LVOL), rvol = VOL && (flags & NODE_RVOL);
+                    bool hl = l != REF_NONE, hr = rr != REF_NONE;
+                    float el = 0.0f, er = 0.0f;
+                    if constexpr (MESH) {
+                        float tl, tr;
+                        const bool sl = slab(lmin, lmax, ray, inv, __builtin_inff(), tl);
+                        const bool sr = slab(rmin, rmax, ray, inv, __builtin_inff(), tr);
+                        const bool gl = (l & (REF_LEAF | REF_PAIR)) != REF_LEAF;
+                        const bool gr = (rr & (REF_LEAF | REF_PAIR)) != REF_LEAF;
+                        el = gl ? tl : 0.0f;
+                        er = gr ? tr : 0.0f;
+                        hl = hl && (!gl || (sl && (lvol || !(tl > best.t))));
+                        hr = hr && (!gr || (sr && (rvol || !(tr > best.t))));
+                    } else {
+                        if (hl && (l & (REF_LEAF | REF_PAIR)) != REF_LEAF) {
+                            hl = slab(lmin, lmax, ray, inv, __builtin_inff(), el);
+                            if (!lvol && el > best.t) hl = false;
+                        }
+                        if (hr && (rr & (REF_LEAF | REF_PAIR)) != REF_LEAF) {
+                            hr = slab(rmin, rmax, ray, inv, __builtin_inff(), er);
+                            if (!rvol && er > best.t) hr = false;
+                        }
+                    }
+                    if (hl && hr) {
+                        bool sw = er < el;
+                        if (lvol && rvol) sw = false;
+                        uint32_t second = sw ? l : rr;
+                        float esecond = sw ? el : er;
+                        if (sw ? lvol : rvol) esecond = -__builtin_inff();
+                        cur = sw ? rr : l;
+                        stk_ref[sp * 64 + lane] = second;
+                        stk_t[sp * 64 + lane] = esecond;
+                        sp++;
+                    } else if (hl) {
+                        cur = l;
+                    } else if (hr) {
+                        cur = rr;
+                    } else {
+                        pop = true;
+                    }
+                }
+                if (pop) {
+                    bool got = false;
+                    while (sp > 0) {
+                        sp--;
+                        uint32_t c = stk_ref[sp * 64 + lane];
+                        float e = stk_t[sp * 64 + lane];
+                        if (e > best.t) continue;
+                        cur = c;
+                        got = true;
+                        break;
+                    }
+                    if (!got) walking = false;
+                }
+            }
+        }
+        // ---- the lanes whose walk has ended: the rest of trace_ray, then the next segment or the next sample ----
+        if (alive && !walking) {
+            Hit h;
+            const bool was_hit = best.leaf != REF_NONE;
+            if (was_hit) finish_leaf<VOL>(p, best, ray, h);
+            V3 term;
+            const bool done = shade_segment(p, was_hit, h, ray, rng, lds_mats, chain, lane, nchain, depth, term);
+            if (done) { // the sample's clamped radiance (render.rs:95-97) goes to memory; k_sum_samples adds them in order
+                const V3 rad = sample_radiance(p, lds_mats, chain, lane, nchain, term);
+                reinterpret_cast<float4 *>(p.samples)[slot] = make_float4(rad.x, rad.y, rad.z, 0.0f);
+                alive = false;
+                need = true;
+            } else {
+                begin_segment();
+            }
+        }
+        fetch_work();
+    }
+
+    unsigned long long total = nseg;
+    for (int off = 32; off > 0; off >>= 1) total += __shfl_xor(total, off, 64);
+    if (lane == 0 && total) atomicAdd(p.counter, total);
+}
+
+
+// Adds each pixel's samples in index order (render.rs:99) and finishes the pixel (render.rs:103-110), or stores the sum.
+// A launch's samples may arrive in several batches (the buffer is bounded): `acc_io` carries the running sums from one
+// batch to the next, so the additions stay those of one loop over all samples.
+__global__ __launch_bounds__(256) void k_sum_samples(const float *samples, uint32_t n_samples, float *acc_io, uint32_t first_batch,
+                                                     uint32_t last_batch, uint32_t spp, uint32_t n_pixels, float *sum_rgba,
+                                                     uint8_t *rgba8, float *mean_rgb) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pixels) return;
+    V3 acc = mk(0.0f, 0.0f, 0.0f);
+    if (!first_batch) {
+        const float4 c = reinterpret_cast<const float4 *>(acc_io)[i];
+        acc = mk(c.x, c.y, c.z);
+    }
+    const float4 *src = reinterpret_cast<const float4 *>(samples) + i;
+    for (uint32_t k = 0; k < n_samples; k++) {
+        const float4 v = src[(uint64_t)k * n_pixels];
+        acc = add(acc, mk(v.x, v.y, v.z));
+    }
+    if (!last_batch) {
+        reinterpret_cast<float4 *>(acc_io)[i] = make_float4(acc.x, acc.y, acc.z, 0.0f);
+        return;
+    }
+    if (sum_rgba) reinterpret_cast<float4 *>(sum_rgba)[i] = make_float4(acc.x, acc.y, acc.z, 0.0f);
+    if (rgba8 || mean_rgb) {
+        const float n = (float)spp;
+        V3 mean = mk(acc.x / n, acc.y / n, acc.z / n);
+        if (mean_rgb) {
+            mean_rgb[3ull * i + 0] = mean.x;
+            mean_rgb[3ull * i + 1] = mean.y;
+            mean_rgb[3ull * i + 2] = mean.z;
+        }
+        if (rgba8) {
+            uint32_t r8 = sat_u8(sqrtf(mean.x) * 255.0f), g8 = sat_u8(sqrtf(mean.y) * 255.0f), b8 = sat_u8(sqrtf(mean.z) * 255.0f);
+            reinterpret_cast<uint32_t *>(rgba8)[i] = r8 | (g8 << 8) | (b8 << 16) | (255u << 24);
+        }
+    }
+}
+
 // render.rs:103-110 for the sharded path: sum -> mean -> sqrt -> RGBA8
 __global__ __launch_bounds__(256) void k_resolve(const float *sum_rgba, uint32_t spp, uint32_t n_pixels, uint8_t *rgba8,
                                                  float *mean_rgb) {
@@ -1371,6 +1628,13 @@ hipError_t launch_render(const RenderParams &p, uint32_t grid, uint32_t lds_byte
         break;
     case WORLD_BVH: // Volume leaves need the reference's visit set and order: a separate instantiation pays for it
         // ... and scenes with meshes get the traversal with unconditional slab tests (see `traverse`)
+        if (p.sample_parallel) {
+            if (p.has_volumes && p.has_meshes) hipLaunchKernelGGL((k_render_bvh_sp<true, true>), dim3(grid), dim3(64), lds_bytes, stream, p);
+            else if (p.has_volumes) hipLaunchKernelGGL((k_render_bvh_sp<true, false>), dim3(grid), dim3(64), lds_bytes, stream, p);
+            else if (p.has_meshes) hipLaunchKernelGGL((k_render_bvh_sp<false, true>), dim3(grid), dim3(64), lds_bytes, stream, p);
+            else hipLaunchKernelGGL((k_render_bvh_sp<false, false>), dim3(grid), dim3(64), lds_bytes, stream, p);
+            break;
+        }
         if (p.resumable_walk) {
             if (p.has_volumes && p.has_meshes) hipLaunchKernelGGL((k_render_bvh<true, true>), dim3(grid), dim3(64), lds_bytes, stream, p);
             else if (p.has_volumes) hipLaunchKernelGGL((k_render_bvh<true, false>), dim3(grid), dim3(64), lds_bytes, stream, p);
@@ -1388,6 +1652,13 @@ hipError_t launch_render(const RenderParams &p, uint32_t grid, uint32_t lds_byte
         else hipLaunchKernelGGL((k_render<WORLD_LINEAR_GENERIC, 0, false, true>), dim3(grid), dim3(64), lds_bytes, stream, p);
         break;
     }
+    return hipGetLastError();
+}
+
+hipError_t launch_sum_samples(const float *samples, uint32_t n_samples, float *acc_io, bool first_batch, bool last_batch, uint32_t spp,
+                              uint32_t n_pixels, float *sum_rgba, uint8_t *rgba8, float *mean_rgb, hipStream_t stream) {
+    hipLaunchKernelGGL(k_sum_samples, dim3((n_pixels + 255u) / 256u), dim3(256), 0, stream, samples, n_samples, acc_io,
+                       first_batch ? 1u : 0u, last_batch ? 1u : 0u, spp, n_pixels, sum_rgba, rgba8, mean_rgb);
     return hipGetLastError();
 }
 
@@ -1420,7 +1691,10 @@ hipError_t render_kernel_attributes(const RenderParams &p, int *vgprs, int *stat
 
 static const void *render_kernel(const RenderParams &p) {
     const void *fn;
-    if (p.world == WORLD_BVH && p.resumable_walk)
+    if (p.world == WORLD_BVH && p.sample_parallel)
+        fn = p.has_volumes ? (p.has_meshes ? reinterpret_cast<const void *>(k_render_bvh_sp<true, true>) : reinterpret_cast<const void *>(k_render_bvh_sp<true, false>))
+                           : (p.has_meshes ? reinterpret_cast<const void *>(k_render_bvh_sp<false, true>) : reinterpret_cast<const void *>(k_render_bvh_sp<false, false>));
+    else if (p.world == WORLD_BVH && p.resumable_walk)
         fn = p.has_volumes ? (p.has_meshes ? reinterpret_cast<const void *>(k_render_bvh<true, true>) : reinterpret_cast<const void *>(k_render_bvh<true, false>))
                            : (p.has_meshes ? reinterpret_cast<const void *>(k_render_bvh<false, true>) : reinterpret_cast<const void *>(k_render_bvh<false, false>));
     else if (p.world == WORLD_BVH)

@@ -531,13 +531,13 @@ def test_tree_kernels_agree_bit_for_bit(builder, w, h):
     frames = {}
     with rt.Renderer(0) as r:
         r.upload_scene(scene)
-        for kernel in ("wave", "resumable", "auto"):
+        for kernel in ("wave", "resumable", "auto", "samples"):
             r.set_option("tree_kernel", kernel)
             rgba, mean = r.render(w, h, seed=77, want_rgba8=True, want_mean=True)
             frames[kernel] = (rgba, mean.view(np.uint32).copy(), r.stats().segments)
         with pytest.raises(rt.RtrError):
             r.set_option("tree_kernel", "fast")
-    for kernel in ("resumable", "auto"):
+    for kernel in ("resumable", "auto", "samples"):
         assert frames[kernel][2] == frames["wave"][2]
         assert np.array_equal(frames[kernel][0], frames["wave"][0]) and np.array_equal(frames[kernel][1], frames["wave"][1])
     o_rgba, o_mean, o_st = pyoracle.OracleScene(scene, trig_mode=pyoracle.TRIG_POLY).render(w, h, 77, threads=0)
@@ -594,3 +594,36 @@ def test_sample_chunks_in_the_sharded_paths(gpu_renderer):
     finally:
         r.set_option("sample_chunks", "auto")
     assert np.array_equal(out["1"][0], out["3"][0]) and np.array_equal(out["1"][1], out["3"][1])
+
+
+def test_sample_parallel_kernel_in_batches_and_sample_shards(gpu_renderer):
+    """tree_kernel = "samples": per-sample radiance goes through device memory and is added per pixel in index order.
+    The sample-sharded launches (what a rank of the multi-GPU path runs) must give the same float4 sums as the resumable
+    kernel, bit for bit, also when the sample range does not start at 0 and with several chunks."""
+    import torch
+
+    r = gpu_renderer
+    scene = house_scene(12)
+    w, h = 104, 60
+    r.upload_scene(scene)
+    dev = torch.device("cuda", 0)
+    out = {}
+    try:
+        for kernel, chunks, batch in (("resumable", "1", "0"), ("samples", "auto", "0"), ("samples", "5", "0"), ("samples", "2", "3"),
+                                      ("samples", "auto", "1")):
+            r.set_option("tree_kernel", kernel)
+            r.set_option("sample_chunks", chunks)
+            r.set_option("samples_batch", batch)
+            a = torch.zeros((h, w, 4), dtype=torch.float32, device=dev)
+            r.render_samples_device(w, h, 9, 3, 8, a.data_ptr(), scene=scene)  # samples [3, 11)
+            torch.cuda.synchronize()
+            rgba, mean = r.render(w, h, seed=9, want_rgba8=True, want_mean=True)  # the fused path, same options
+            out[(kernel, chunks, batch)] = (a.cpu().numpy().view(np.uint32).copy(), r.stats().segments, rgba, mean.view(np.uint32).copy())
+    finally:
+        r.set_option("tree_kernel", "auto")
+        r.set_option("sample_chunks", "auto")
+        r.set_option("samples_batch", "0")
+    base = out[("resumable", "1", "0")]
+    for key, val in out.items():
+        assert val[1] == base[1], key
+        assert np.array_equal(val[0], base[0]) and np.array_equal(val[2], base[2]) and np.array_equal(val[3], base[3]), key
