@@ -1079,11 +1079,14 @@ __global__ __launch_bounds__(64, RTR_X_WAVES_PER_EU) void k_render(const RenderP
 #define RTR_X_WALK_UNROLL 4
 #endif
 constexpr uint32_t kWalkUnroll = RTR_X_WALK_UNROLL;
+#ifndef RTR_X_BVH_SGPRS
+#define RTR_X_BVH_SGPRS 96
+#endif
 #ifndef RTR_X_BVH_WAVES
 #define RTR_X_BVH_WAVES 7 // 72 VGPRs without spills (the compiler takes 75 unasked): 7 waves per SIMD, +0 ... +5 %
 #endif
 template <bool VOL, bool MESH>
-__attribute__((amdgpu_num_sgpr(96)))
+__attribute__((amdgpu_num_sgpr(RTR_X_BVH_SGPRS)))
 __global__ __launch_bounds__(64, RTR_X_BVH_WAVES) void k_render_bvh(const RenderParams p) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const uint32_t lane = threadIdx.x;
@@ -1299,9 +1302,10 @@ __global__ __launch_bounds__(64, RTR_X_BVH_WAVES) void k_render_bvh(const Render
 // counter as they finish; each sample's clamped radiance is written to p.samples[sample][pixel], and k_sum_samples adds
 // a pixel's samples in index order afterwards (the same additions as calculate_pixel's loop).  No lane waits for its
 // tile's slowest pixel, and sample ranges need no hand-over between workgroups.
+// 6 waves per SIMD and 128 SGPRs: 80 VGPRs without the spills the 7-wave budget forces on this kernel (+4 ... 5 %)
 template <bool VOL, bool MESH>
-__attribute__((amdgpu_num_sgpr(96)))
-__global__ __launch_bounds__(64, RTR_X_BVH_WAVES) void k_render_bvh_sp(const RenderParams p) {
+__attribute__((amdgpu_num_sgpr(128)))
+__global__ __launch_bounds__(64, 6) void k_render_bvh_sp(const RenderParams p) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const uint32_t lane = threadIdx.x;
     const uint32_t chunk = blockIdx.x / p.tiles_launch, tidx = blockIdx.x - chunk * p.tiles_launch;
