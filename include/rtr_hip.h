@@ -208,8 +208,9 @@ int rtr_abi_version(void);
  *                 walk, but a lane takes (sample, pixel) pairs of its tile instead of owning one pixel; each sample's
  *                 clamped radiance is written to device memory (16 bytes per sample, in batches of at most 16 GiB)
  *                 and a second kernel adds every pixel's samples in index order.  Every lane-level operation and
- *                 every addition is the same in all three: bit-identical frames.  "auto": scenes with meshes take
- *                 "samples" (inside tile-sharded launches, where it does not apply: "resumable"), others "wave". */
+ *                 every addition is the same in all three: bit-identical frames.  "auto": trees of 32 leaves or more
+ *                 take "samples" (inside tile-sharded launches, where it does not apply: "resumable" for scenes with
+ *                 meshes, else "wave"); smaller trees "wave". */
 /*   "samples_batch" = "0" (default: as many samples as 16 GiB hold) | N: samples per batch of the "samples" kernel's
  *                 radiance buffer; a pixel's running sum is carried from batch to batch, so any N gives the same frame. */
 /*   "sample_chunks" = "auto" (default) | "1" .. "4096" (applied at the next render): pieces every pixel's sample range

@@ -177,9 +177,9 @@ int launch_frame(rtr_context *ctx, const rtr_camera *camera, const rtr_settings 
     // through HBM (k_render_bvh_sp + k_sum_samples).  Needs a tree world, something to trace and the fused or
     // sample-sharded path (a tile shard writes into a frame other shards share); otherwise the resumable / wave rule.
     // Measured at 1080p/64 spp against the resumable walk: C3 +19 %, C4 +16 %, C1 +10 %.
-    // Sphere-only trees keep the wave kernel under "auto": the per-sample set-up and the trip through memory do not pay
-    // for their cheap samples (5-sphere tree -14 %, 102 spheres +6 % at 1080p but -4 % at 4K).
-    p.sample_parallel = ((ctx->tree_kernel == 3 || (ctx->tree_kernel == 0 && fs.n_triangles > 0u)) && st->enable_bvh_tree &&
+    // Tiny trees keep the wave kernel under "auto": the per-sample set-up and the trip through memory do not pay for
+    // their cheap samples (5-sphere tree -13 %; 102 spheres +8 % at 1080p, +1 % at 4K; meshes +20 %).
+    p.sample_parallel = ((ctx->tree_kernel == 3 || (ctx->tree_kernel == 0 && fs.leaf_hot.size() >= 32u)) && st->enable_bvh_tree &&
                          p.max_depth > 0u && sample_count > 0u && n_shards == 1u) ? 1u : 0u;
     if (ctx->tree_kernel == 3 && !p.sample_parallel) p.resumable_walk = 1u;
     p.root_ref = fs.root_ref;
