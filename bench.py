@@ -6,20 +6,27 @@
     workload scenes/benchmark.json at 1920x1080, 256 spp, depth 6, clamp 10 (BASELINE configs[1])
     step     one whole frame: integrate + clamp + mean + sqrt gamma + RGBA8, output resident in HBM
 
-N = 1: one fused kernel per frame.  N > 1 (one process per GPU, launched by torch.distributed.run): the samples
-of every pixel are split over the ranks (each rank integrates all pixels for its share of the samples, so every GPU
-keeps a full grid of short waves), the per-pixel partial sums are summed onto rank 0 with one RCCL reduce over
-xGMI, rank 0 resolves to RGBA8; frame i's reduce overlaps frame i+1's integrate.  `--split tiles` selects the
-8x8-tile decomposition instead (bit-identical to one GPU, but under-fills the GPUs).  The total work is the fixed
-frame, so scaling is "strong".
+N = 1: one fused kernel per frame.  N > 1: one process per GPU.  `python bench.py --gpus N` launches the N ranks
+itself (python -m torch.distributed.run, rendezvous on 127.0.0.1) before anything touches a GPU; started by a
+launcher (WORLD_SIZE set) it is one of the ranks.  The samples of every pixel are split over the ranks (each rank
+integrates all pixels for its share of the samples, so every GPU keeps a full grid of short waves), the per-pixel
+partial sums are summed onto rank 0 with one RCCL reduce over xGMI, rank 0 resolves to RGBA8; frame i's reduce
+overlaps frame i+1's integrate.  `--split tiles` selects the 8x8-tile decomposition instead (bit-identical to one
+GPU, but under-fills the GPUs).  The total work is the fixed frame, so scaling is "strong".
 
-Prints ONE JSON line on rank 0.
+Prints ONE JSON line on rank 0.  The `roofline` object names the bound that binds this path -- VALU instruction
+issue (there is no dense contraction and the scene is cache resident: DESIGN.md section 5) -- from counters of a
+rocprofv3 run of the same command on the same kernel build (profiles/, stamped with the kernel sources' hash; null
+when the build has changed since), with the measured HBM traffic beside it.  At N = 1 the CPU leg renders the same
+seed as one GPU frame and the two are compared byte for byte (`config.parity_full_frame`).
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -27,49 +34,19 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 # algorithmic bytes per ray segment, SURVEY.md section 8(d): 96 (path state in+out) + 20 per sphere tested
-# + 32 per node + 48 per triangle (+12 per SkyMap texel); linear world of benchmark.json: 5 spheres, no nodes
-BYTES_PER_SEGMENT_C2 = 96 + 20 * 5
-# the other configurations: N_node / N_sph / N_tri / sky fraction per segment measured by the oracle under the
-# reference's unculled traversal (scripts/bench_configs.py prints them), folded into B_seg
+# + 32 per node + 48 per triangle (+12 per SkyMap texel); N_node / N_sph / N_tri / sky fraction per segment measured
+# by the oracle under the reference's unculled traversal (scripts/bench_configs.py prints them).  A streaming-wavefront
+# MODEL: this design keeps path state in registers, so the figure is reported as an auxiliary, never as the roofline.
 BYTES_PER_SEGMENT = {"c2": 196.0, "c1": 1032.6, "c2b": 317.5, "c3": 1240.7, "c3l": 937.2, "c4": 1480.6, "c5": 1038.4}
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
+# One wave64 VALU instruction occupies a SIMD-32 for 2 cycles: 256 CUs x 4 SIMDs x 2.4 GHz / 2 (MI355X_MICROARCH.md,
+# "Wave scheduling" and the cycle-constants table).  Half-rate (compare / select / integer multiply) and quarter-rate
+# (sqrt / rcp) instructions and the clock the chip holds under load (< 2.4 GHz) keep 1.0 out of reach.
+VALU_PEAK_WAVE_INSTS_PER_S = 256 * 4 * 2.4e9 / 2.0
+PROFILE_ROUND = "r02"
 
 
-def committed_pmc(args, world):
-    """Counters of the headline kernel from the committed rocprofv3 PMC passes (profiles/r01/traffic.json): they
-    cannot be read inside this process, so the figures of the same command's profile run are reported."""
-    if world != 1 or args.config or (args.width, args.height, args.spp) != (1920, 1080, 256) or args.bvh:
-        return None
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01", "traffic.json")) as fh:
-            return json.load(fh)
-    except (OSError, ValueError):
-        return None
-
-
-def pmc_traffic(args, world):
-    if args.pmc_traffic is not None:
-        return args.pmc_traffic
-    d = committed_pmc(args, world)
-    return float(d["bytes_per_launch"]) if d and "bytes_per_launch" in d else None
-
-
-def valu_issue(args, world, kernel_ms):
-    """The bound that actually binds: VALU issue.  One wave64 VALU instruction occupies a SIMD-32 for >= 2 cycles,
-    so the chip issues at most 1024 SIMDs x 2.4e9 / 2 wave-instructions per second (MI355X_MICROARCH.md)."""
-    d = committed_pmc(args, world)
-    if not d or "sq_insts_valu_per_launch" not in d or kernel_ms <= 0:
-        return None
-    peak = 1024 * 2.4e9 / 2.0
-    ach = float(d["sq_insts_valu_per_launch"]) / (kernel_ms * 1e-3)
-    return {"wave_insts_per_launch": float(d["sq_insts_valu_per_launch"]), "achieved_per_s": round(ach, 0),
-            "peak_per_s": peak, "frac": round(ach / peak, 4),
-            "active_lane_fraction": d.get("active_lane_fraction"),  # SQ_THREAD_CYCLES_VALU / (SQ_ACTIVE_INST_VALU * 64)
-            "source": "SQ_INSTS_VALU from profiles/r01 (same command), kernel time from this run's HIP events; "
-                      "half-rate (compare/select/int-mul) and quarter-rate (sqrt/rcp) instructions make 1.0 unreachable"}
-
-
-def parse_args():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
@@ -93,13 +70,144 @@ def parse_args():
                     help="mesh subtrees: the reference's median split (parity) or the binned-SAH rebuild (faster walk)")
     ap.add_argument("--scene-tree", choices=["reference", "sah"], default="reference",
                     help="scene-level tree over the objects: the reference's median split (parity) or binned SAH")
-    ap.add_argument("--pmc-traffic", type=float, default=None,
-                    help="HBM bytes per launch from a separate rocprofv3 --pmc pass (profiles/), if collected")
-    return ap.parse_args()
+    ap.add_argument("--tree-kernel", default=None, help="rtr_set_option tree_kernel (auto, wave, resumable, samples, pool)")
+    return ap.parse_args(argv)
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# N > 1 without a launcher: start the ranks
+# ---------------------------------------------------------------------------------------------------------------
+def plumbing_mode() -> bool:
+    """RTR_BENCH_PLUMBING=1 (tests/test_bench_contract.py): the rank processes run on the CPU over gloo with a
+    stand-in integrator, so that launching, rendezvous, sample ranges and the reduce can be exercised without GPUs."""
+    return os.environ.get("RTR_BENCH_PLUMBING") == "1"
+
+
+def free_port() -> int:
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return int(s.getsockname()[1])
+
+
+def spawn_ranks(args) -> int:
+    """Called before any HIP / torch.cuda use in this process: starts args.gpus fresh rank processes (never re-execs a
+    process that has touched the GPU) and returns their exit code.  Rank 0 prints the JSON line on the shared stdout."""
+    if not plumbing_mode():
+        import torch
+
+        have = torch.cuda.device_count()  # counts devices without initialising one (brief, Environment)
+        if have < args.gpus:
+            sys.stderr.write(f"bench.py: --gpus {args.gpus} but only {have} GPU(s) are visible; refusing to run on fewer\n")
+            return 2
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
+def plumbing_rank(args, world, rank) -> int:
+    """The CPU stand-in of a rank (see plumbing_mode): same launch, rendezvous, sample split, reduce and JSON contract."""
+    import torch
+    import torch.distributed as dist
+
+    from raytracingrust_amd.distributed import sample_range
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    begin, count = sample_range(rank, world, args.spp)
+    w, h = 16, 8
+    # stand-in integrate: sample s of pixel p contributes (p + 1) * (s + 1) -- an exact small-integer sum in f32
+    pix = torch.arange(1, w * h + 1, dtype=torch.float32).reshape(h, w, 1).repeat(1, 1, 4)
+    part = pix * float(sum(s + 1 for s in range(begin, begin + count)))
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        acc = part.clone()
+        dist.reduce(acc, dst=0, op=dist.ReduceOp.SUM)
+    dist.barrier()
+    elapsed = time.perf_counter() - t0
+    ranges = [None] * world
+    dist.all_gather_object(ranges, (begin, count))
+    if rank == 0:
+        want = pix * float(args.spp * (args.spp + 1) // 2)
+        print(json.dumps({"metric": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "plumbing": True, "sample_ranges": ranges, "reduce_matches_single_rank": bool(torch.equal(acc, want)),
+                          "ms_per_step": round(elapsed * 1e3 / max(args.steps, 1), 4)}), flush=True)
+    dist.destroy_process_group()
+    return 0
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# counters of the rocprofv3 run (profiles/), stamped with the hash of the kernel sources they were taken on
+# ---------------------------------------------------------------------------------------------------------------
+def workload_key(args, W, H):
+    name = args.config or ("c2b" if args.bvh else "c2")
+    if not args.config and os.path.basename(args.scene) != "benchmark.json":
+        name = os.path.splitext(os.path.basename(args.scene))[0]
+    key = f"{name}_{W}x{H}_{args.spp}spp"
+    if args.mesh_tree == "sah" or args.scene_tree == "sah":
+        key += "_sah"
+    if args.tree_kernel:
+        key += "_" + args.tree_kernel
+    return key
+
+
+def committed_profile(args, W, H, world):
+    """(dict | None, status): the PMC summary scripts/profile_bench.sh wrote for this workload, if it was taken on
+    the kernel sources this process runs."""
+    if world != 1:
+        return None, "single-GPU profile only"
+    from raytracingrust_amd.build import kernel_sha
+
+    path = os.path.join(ROOT, "profiles", PROFILE_ROUND, workload_key(args, W, H) + ".json")
+    try:
+        with open(path) as fh:
+            d = json.load(fh)
+    except (OSError, ValueError):
+        return None, "no profile for this workload under profiles/" + PROFILE_ROUND
+    if d.get("kernel_sha") != kernel_sha():
+        return None, f"stale: profiled at kernel_sha {d.get('kernel_sha')}, running {kernel_sha()}"
+    return d, "profiles/%s/%s.json" % (PROFILE_ROUND, workload_key(args, W, H))
+
+
+def roofline_block(prof, prof_status, integrate_ms, alg_bytes, kernel_name):
+    """Flat scalars only.  bound = VALU issue; the HBM side is what the counters measured, not a model."""
+    out = {"bound": "valu_issue", "achieved": None, "peak": round(VALU_PEAK_WAVE_INSTS_PER_S / 1e9, 1),
+           "unit": "G wave-instructions/s", "frac": None, "traffic": None,
+           "active_lane_fraction": None, "lane_throughput_frac": None,
+           "hbm_achieved_gbs": None, "hbm_peak_gbs": HBM_PEAK_GBS, "hbm_frac_measured": None,
+           "kernel": kernel_name, "kernel_ms_hip_events": round(integrate_ms, 4),
+           "counters": prof_status,
+           "aux_streaming_model_gbs": round(alg_bytes / (integrate_ms * 1e-3) / 1e9, 1) if integrate_ms > 0 else None,
+           "aux_streaming_model_note": "SURVEY 8(d)'s algorithmic bytes (48 B of path state in and out per segment + "
+                                       "geometry records) over the kernel time: a model of a streaming design, bytes "
+                                       "this register-resident kernel never moves; not a bound"}
+    if prof is None or integrate_ms <= 0:
+        return out
+    t = integrate_ms * 1e-3
+    ach = float(prof["sq_insts_valu"]) / t
+    out["achieved"] = round(ach / 1e9, 1)
+    out["frac"] = round(ach / VALU_PEAK_WAVE_INSTS_PER_S, 4)
+    if prof.get("active_lane_fraction") is not None:
+        out["active_lane_fraction"] = round(float(prof["active_lane_fraction"]), 4)
+        out["lane_throughput_frac"] = round(out["frac"] * out["active_lane_fraction"], 4)
+    if prof.get("hbm_bytes_per_launch") is not None:
+        out["traffic"] = float(prof["hbm_bytes_per_launch"])
+        out["hbm_achieved_gbs"] = round(out["traffic"] / t / 1e9, 2)
+        out["hbm_frac_measured"] = round(out["traffic"] / t / 1e9 / HBM_PEAK_GBS, 5)
+    out["kernel_avg_ms_rocprof"] = round(float(prof.get("kernel_avg_ns_rocprof", 0.0)) / 1e6, 4)
+    out["vgprs_profiled"] = prof.get("vgpr")
+    out["sgprs_profiled"] = prof.get("sgpr")
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# CPU leg: the oracle on this host's cores, and the byte-for-byte check of one GPU frame against it
+# ---------------------------------------------------------------------------------------------------------------
 def cpu_baseline(scene, width, height, spp_sample, seed):
-    """The oracle ("port": C restatement, reference not runnable -- no Rust toolchain) on this host's cores."""
+    """The oracle ("port": C restatement, reference not runnable -- no Rust toolchain) on this host's cores.
+    Returns (record, rgba8 of the rendered sample, its spp, its segment count)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import copy
 
@@ -111,32 +219,43 @@ def cpu_baseline(scene, width, height, spp_sample, seed):
     if spp_sample <= 0:
         # size the sample for roughly 15 s of CPU work: probe at 2 spp, then scale (never above the real spp)
         sc.settings.samples_per_pixel = 2
-        _, _, pr = pyoracle.OracleScene(sc).render(width, height, seed, threads=cores, want_rgba8=True, want_mean=False)
+        _, _, pr = pyoracle.OracleScene(sc, trig_mode=pyoracle.TRIG_POLY).render(width, height, seed, threads=cores, want_rgba8=True, want_mean=False)
         spp_sample = int(max(2, min(scene.settings.samples_per_pixel, round(15.0 / max(pr.seconds / 2.0, 1e-6)))))
     sc.settings.samples_per_pixel = spp_sample
-    _, _, st = pyoracle.OracleScene(sc).render(width, height, seed, threads=cores, want_rgba8=True, want_mean=False)
-    return {
+    rgba, _, st = pyoracle.OracleScene(sc, trig_mode=pyoracle.TRIG_POLY).render(width, height, seed, threads=cores, want_rgba8=True, want_mean=False)
+    rec = {
         "value": round(st.segments / st.seconds / 1e6, 3), "unit": "Mrays/s", "cores": int(st.threads), "kind": "port",
         "sample": f"full {width}x{height} frame at {spp_sample} spp (of {scene.settings.samples_per_pixel}), "
                   f"{st.segments} segments in {st.seconds:.2f} s; C restatement of the reference "
-                  f"(reference itself not runnable: no Rust toolchain)",
+                  f"(reference itself not runnable: no Rust toolchain; parity unpinned: the reference holds no fixtures)",
         "ms_per_frame_extrapolated": round(st.seconds * 1e3 * scene.settings.samples_per_pixel / spp_sample, 1),
     }
+    return rec, rgba, spp_sample, int(st.segments)
 
 
 def main():
     args = parse_args()
+    world_env = os.environ.get("WORLD_SIZE")
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if world_env is None and args.gpus > 1:
+        sys.exit(spawn_ranks(args))  # nothing in this process has touched a GPU
+    world = int(world_env or "1")
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: start one rank per GPU (or let bench.py start them: "
+                         f"run it without a launcher)")
+    if plumbing_mode():
+        sys.exit(plumbing_rank(args, world, rank))
+
+    import numpy as np
     import torch
     import torch.distributed as dist
 
     import raytracingrust_amd as rt
     from raytracingrust_amd.distributed import FramePipeline
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     # RTR_BENCH_FORCE_DISTRIBUTED=1 (testing aid): take the sharded + RCCL-reduce path even with one rank
     distributed = world > 1 or os.environ.get("RTR_BENCH_FORCE_DISTRIBUTED") == "1"
     torch.cuda.set_device(local_rank)
@@ -151,17 +270,20 @@ def main():
         from raytracingrust_amd.configs import baseline_config
 
         scene, W, H = baseline_config(args.config, args.spp)
-        args.scene = args.config
+        scene_name = args.config
     else:
         scene = rt.Scene.from_file(args.scene)
         scene.settings.samples_per_pixel = args.spp
         if args.bvh:
             scene.settings.enable_bvh_tree = True
         W, H = args.width, args.height
+        scene_name = os.path.basename(args.scene)
 
     r = rt.Renderer(local_rank)
     r.set_option("mesh_tree", args.mesh_tree)
     r.set_option("scene_tree", args.scene_tree)
+    if args.tree_kernel:
+        r.set_option("tree_kernel", args.tree_kernel)
     r.upload_scene(scene)
     rgba8 = torch.zeros((H, W, 4), dtype=torch.uint8, device=dev)
     # N > 1: double-buffered integrate | RCCL reduce + resolve pipeline (raytracingrust_amd/distributed.py)
@@ -177,7 +299,7 @@ def main():
         if not distributed:
             r.render_frame_device(W, H, seed, rgba8.data_ptr(), stream)
         else:
-            # zero -> integrate own tiles -> RCCL reduce(SUM) to rank 0 -> resolve on rank 0, frame i's reduce
+            # integrate own samples (or tiles) -> RCCL reduce(SUM) to rank 0 -> resolve on rank 0, frame i's reduce
             # overlapping frame i+1's integrate
             pipe.submit(seed)
 
@@ -198,11 +320,13 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
 
-    # device-side counters / HIP-event kernel times of the timed launches
+    # device-side counters / HIP-event kernel times of the timed launches (rtr_* raise if a launch set the fault word)
     ktimes = r.kernel_times_ms()[-args.steps:]
+    itimes = r.integrate_times_ms()[-args.steps:]
     segs = r.segment_counts()[-args.steps:]
     my_segments = float(segs.sum())
     my_kernel_ms = float(ktimes.mean()) if len(ktimes) else 0.0
+    my_integrate_ms = float(itimes.mean()) if len(itimes) else 0.0
     stats = r.stats()
 
     t = torch.tensor([elapsed, my_segments, my_kernel_ms], dtype=torch.float64, device=dev)
@@ -222,44 +346,51 @@ def main():
         ms_per_step = elapsed * 1e3 / args.steps
         mrays = total_segments / elapsed / 1e6
         seg_per_launch = my_segments / max(args.steps, 1)  # rank 0's kernel (N=1: the whole frame)
-        pixels_per_launch = stats.primary_samples / max(args.spp, 1)
-        b_seg = BYTES_PER_SEGMENT.get(args.config, BYTES_PER_SEGMENT_C2) if args.config else (
-            BYTES_PER_SEGMENT["c2b"] if args.bvh else BYTES_PER_SEGMENT_C2)
+        pixels_per_launch = stats.primary_samples / max(args.spp // world if (distributed and pipe.split == "samples") else args.spp, 1)
+        b_seg = BYTES_PER_SEGMENT.get(args.config, BYTES_PER_SEGMENT["c2"]) if args.config else (
+            BYTES_PER_SEGMENT["c2b"] if args.bvh else BYTES_PER_SEGMENT["c2"])
         alg_bytes = b_seg * seg_per_launch + 4.0 * pixels_per_launch
-        achieved = alg_bytes / (my_kernel_ms * 1e-3) / 1e9 if my_kernel_ms > 0 else 0.0
+        prof, prof_status = committed_profile(args, W, H, world)
         out = {
             "metric": "Mrays/s", "value": round(mrays, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {
-                "workload": f"{os.path.basename(args.scene)} {W}x{H} {args.spp}spp depth {scene.settings.max_ray_depth} "
+                "workload": f"{scene_name} {W}x{H} {args.spp}spp depth {scene.settings.max_ray_depth} "
                             f"clamp {scene.settings.clamp_indirect:g} "
                             f"{'BVH' if scene.settings.enable_bvh_tree else 'linear'} world",
                 "sharding": "single fused kernel" if pipe is None else (
                     f"samples of every pixel split over {world} ranks + RCCL reduce (sum of partial sums)"
                     if pipe.split == "samples" else f"8x8 tiles round-robin over {world} ranks + RCCL reduce"),
+                "mesh_tree": args.mesh_tree, "scene_tree": args.scene_tree,
                 "ms_per_frame": round(ms_per_step, 4),
                 "msamples_per_s": round(W * H * args.spp * args.steps / elapsed / 1e6, 2),
                 "segments_per_frame": int(total_segments / max(args.steps, 1)),
                 "kernel_ms": round(kernel_ms, 4), "vgprs": int(stats.vgprs), "lds_bytes_per_wave": int(stats.lds_bytes),
+                "parity": "unpinned (the reference holds no fixtures and cannot be built here); checked against oracle/",
             },
-            "roofline": {
-                "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(args, world),
-                "kernel": "k_render<linear spheres>" if not scene.settings.enable_bvh_tree else "k_render<bvh>",
-                "algorithmic_bytes_per_launch": int(alg_bytes), "bytes_per_segment": b_seg,
-                "kernel_ms_hip_events": round(my_kernel_ms, 4),
-                "valu_issue": valu_issue(args, world, my_kernel_ms),
-                "note": "algorithmic bytes are SURVEY 8(d)'s streaming-wavefront model (48 B of path state in and out "
-                        "per segment + geometry records); this kernel keeps path state in registers and the scene in "
-                        "SGPRs/LDS/L1, so measured HBM traffic is the framebuffer plus the running sums handed between "
-                        "sample chunks (~0.17 GB per launch) and frac can exceed 1: the kernel is VALU-issue bound "
-                        "(DESIGN.md section 5)",
-            },
+            "roofline": roofline_block(prof, prof_status, my_integrate_ms, alg_bytes, r.kernel_name()),
         }
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(scene, W, H, args.cpu_spp, args.seed)
-            out["config"]["gpu_over_cpu"] = round(mrays / max(out["cpu_baseline"]["value"], 1e-9), 1)
+            rec, o_rgba, o_spp, o_segments = cpu_baseline(scene, W, H, args.cpu_spp, args.seed)
+            out["cpu_baseline"] = rec
+            out["config"]["gpu_over_cpu"] = round(mrays / max(rec["value"], 1e-9), 1)
+            # the same seed, size and spp on the GPU, compared byte for byte and segment for segment
+            import copy
+
+            sc = copy.copy(scene)
+            sc.settings = copy.copy(scene.settings)
+            sc.settings.samples_per_pixel = o_spp
+            r.render_frame_device(W, H, args.seed, rgba8.data_ptr(), stream, scene=sc)
+            torch.cuda.synchronize()
+            g_segments = int(r.segment_counts()[-1])
+            g_rgba = rgba8.cpu().numpy()
+            bad_px = int(np.count_nonzero(np.any(g_rgba != o_rgba, axis=-1)))
+            max_diff = int(np.max(np.abs(g_rgba.astype(np.int16) - o_rgba.astype(np.int16)))) if bad_px else 0
+            out["config"]["parity_full_frame"] = ("bit-exact" if bad_px == 0 and g_segments == o_segments else "MISMATCH")
+            out["config"]["parity_full_frame_detail"] = (
+                f"{W}x{H} at {o_spp} spp, seed {args.seed:#x}: {bad_px} of {W * H} RGBA8 pixels differ (max channel "
+                f"difference {max_diff}); segments GPU {g_segments} vs oracle {o_segments}")
         print(json.dumps(out), flush=True)
     r.close()
     if distributed:

@@ -217,7 +217,15 @@ int rtr_abi_version(void);
  *                 is cut into inside one launch.  Each piece continues the running sums of the one before it in the
  *                 same order, so the frame is bit-identical for every value; more pieces shorten the tail of a launch
  *                 that has few tiles per resident wave (1080p: -9 % with 4) and cost a workgroup prologue each.
- *                 Launches of one context that use chunks share scratch buffers: issue them on one stream. */
+ *   "chunk_timeout_ms" = "10000" (default) | milliseconds: how long a piece waits for the piece before it.  HIP does
+ *                 not promise dispatch order, so the wait is bounded; a piece that gives up sets the context's device
+ *                 fault word and the next synchronising call (rtr_render*, rtr_get_stats, rtr_kernel_times_ms,
+ *                 rtr_segment_counts) returns RTR_ERR_HIP once: the frames rendered since the previous such call
+ *                 are invalid.
+ *   "debug_fault" = "off" (default) | "on": testing aid; launches set the fault word themselves.
+ * Scratch shared by the launches of ONE context: the running sums and counters of sample chunks, the radiance buffer
+ * and running sums of the "samples" tree kernel, the event / counter ring.  Issue a context's launches on one stream
+ * (or order them with events); use one context per stream for concurrent frames. */
 int rtr_set_option(rtr_context *ctx, const char *name, const char *value);
 /* Lower + build + flatten + copy to HBM.  Replaces any previous scene of the context. */
 int rtr_upload_scene(rtr_context *ctx, const rtr_scene_desc *scene);
@@ -261,11 +269,18 @@ int rtr_render_samples_device(rtr_context *ctx, const rtr_camera *camera, const 
 int rtr_resolve_device(rtr_context *ctx, const float *d_sum_rgba, uint32_t samples_per_pixel, uint32_t width,
                        uint32_t height, uint8_t *d_rgba8, float *d_mean_rgb, void *stream);
 
-/* Waits for the context's outstanding work, then reports counters and HIP-event timings. */
+/* Waits for the context's outstanding work, then reports counters and HIP-event timings.  Like rtr_kernel_times_ms
+ * and rtr_segment_counts it returns RTR_ERR_HIP (once) when a launch since the last synchronising call set the device
+ * fault word (option "chunk_timeout_ms"): the asynchronous entry points cannot report that themselves. */
 int rtr_get_stats(rtr_context *ctx, rtr_stats *out);
 /* HIP-event durations (ms) of the most recent render kernels, oldest first; returns how many were written
  * (at most cap, at most 64).  Waits for outstanding work. */
 int rtr_kernel_times_ms(rtr_context *ctx, float *out, uint32_t cap);
+/* The same launches: HIP-event time from the start of each launch to the end of its (last) integrate kernel, i.e.
+ * without the k_sum_samples pass of the "samples" tree kernel.  bench.py prices the dominant kernel with it. */
+int rtr_integrate_times_ms(rtr_context *ctx, float *out, uint32_t cap);
+/* Name of the integrate kernel the most recent render launched (as rocprofv3 lists it, with a gloss). */
+const char *rtr_kernel_name(const rtr_context *ctx);
 /* Device self-test: the kernels' correctly-rounded square root (csrc/rtr_kernels.hip rt_sqrt) against the
  * compiler's sqrtf() over all 2^32 f32 bit patterns; *mismatches must come back 0. */
 int rtr_selftest_sqrt(rtr_context *ctx, uint64_t *mismatches);

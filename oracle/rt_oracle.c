@@ -99,7 +99,11 @@ static inline hit_t hit_new(v3 point, v3 outward_normal, float t, const ray_t *r
 /* Random numbers.  The reference draws from rand::thread_rng() everywhere (render.rs:80,
  * materials.rs:127,151, sample.rs:60,78, volume.rs:57): OS-seeded, so nothing can pin its values.
  * We substitute one counter-keyed stream per (seed, pixel, sample): a 32-bit PCG (RXS-M-XS output,
- * per-pixel odd increment).  The float conversions are rand 0.8's (top 23 bits).            */
+ * per-pixel odd increment); both halves of the seed are hashed into both stream keys, so frames of
+ * different seeds are never pixel permutations of each other.  The rejection sampler's candidates
+ * (sample.rs:43-51) come from a sub-stream: one word of the path's stream seeds a plain 32-bit LCG
+ * whose successive states are the coordinates (or_ball_coord).  The float conversions are rand 0.8's
+ * (top 23 bits).                                                                              */
 typedef struct { uint32_t state, inc; uint64_t draws; } or_rng;
 
 static inline uint32_t or_hash32(uint32_t x) {
@@ -107,7 +111,8 @@ static inline uint32_t or_hash32(uint32_t x) {
     return x;
 }
 static inline void or_rng_seed(or_rng *r, uint64_t seed, uint32_t pixel, uint32_t sample) {
-    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    uint32_t lo = (uint32_t)seed, hi = (uint32_t)(seed >> 32);
+    uint32_t k0 = or_hash32(lo ^ or_hash32(hi + 0x9E3779B9u)), k1 = or_hash32(hi ^ or_hash32(lo + 0x85EBCA6Bu));
     uint32_t hp = or_hash32(pixel ^ k0);
     r->inc = (or_hash32(hp + k1) << 1) | 1u;
     r->state = or_hash32(hp + sample * 0x9E3779B9u);
@@ -125,8 +130,12 @@ static inline float or_rng_value01(or_rng *r) { return (float)(or_rng_u32(r) >> 
 static inline float or_rng_unit_inclusive(or_rng *r) { return or_rng_value01(r) * 0x1.000002p+0f + 0.0f; }
 /* gen_range(0.0..1.0) (materials.rs:127,151) */
 static inline float or_rng_unit(or_rng *r) { return or_rng_value01(r) * 1.0f + 0.0f; }
-/* gen_range(-1.0..1.0) (sample.rs:29-31 via CubeSampler::from_range(-1.0..=1.0)) */
-static inline float or_rng_signed(or_rng *r) { return or_rng_value01(r) * 2.0f + -1.0f; }
+/* gen_range(-1.0..1.0) (sample.rs:29-31 via CubeSampler::from_range(-1.0..=1.0)) on the next state of the
+ * rejection sampler's LCG sub-stream: value0_1 * 2 + -1 with value0_1 = (top 23 bits) * 2^-23 */
+static inline float or_ball_coord(uint32_t *s) {
+    *s = *s * 747796405u + 2891336453u;
+    return ((float)(*s >> 9) * 0x1p-23f) * 2.0f + -1.0f;
+}
 
 /* ------------------------------------------------------------------------------------------ */
 /* lib/utils/aabb.rs */
@@ -472,8 +481,9 @@ static inline v3 refract(v3 uv, v3 n, float etai_over_etat) {                   
 
 /* lib/utils/sample.rs:26-79 */
 static v3 sample_unit_sphere_volume(or_rng *rng) { /* sample.rs:43-51 */
+    uint32_t s = or_rng_u32(rng); /* one word of the path's stream per call, whatever the number of rejections */
     for (;;) {
-        float x = or_rng_signed(rng), y = or_rng_signed(rng), z = or_rng_signed(rng);
+        float x = or_ball_coord(&s), y = or_ball_coord(&s), z = or_ball_coord(&s);
         v3 v = v3_new(x, y, z);
         if (v3_mag2(v) <= 1.0f) return v;
     }
@@ -1001,7 +1011,11 @@ void or_probe_rng(uint64_t seed, uint32_t pixel, uint32_t sample, int kind, floa
     or_rng r; r.draws = 0;
     or_rng_seed(&r, seed, pixel, sample);
     for (int i = 0; i < n; i++)
-        out[i] = kind == 0 ? or_rng_unit_inclusive(&r) : (kind == 1 ? or_rng_unit(&r) : or_rng_signed(&r));
+        out[i] = kind == 0 ? or_rng_unit_inclusive(&r) : (kind == 1 ? or_rng_unit(&r) : 0.0f);
+    if (kind == 2) { /* the coordinates the rejection sampler would test, in order */
+        uint32_t s = or_rng_u32(&r);
+        for (int i = 0; i < n; i++) out[i] = or_ball_coord(&s);
+    }
 }
 float or_probe_acos(float x, int trig_mode) { return or_acos(x, trig_mode); }
 float or_probe_atan2(float y, float x, int trig_mode) { return or_atan2(y, x, trig_mode); }

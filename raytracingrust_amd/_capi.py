@@ -105,6 +105,8 @@ SYMBOLS = [
     ("rtr_get_stats", C.c_int, [_ctx, C.POINTER(rtr_stats)]),
     ("rtr_kernel_times_ms", C.c_int, [_ctx, C.POINTER(C.c_float), C.c_uint32]),
     ("rtr_segment_counts", C.c_int, [_ctx, C.POINTER(C.c_uint64), C.c_uint32]),
+    ("rtr_integrate_times_ms", C.c_int, [_ctx, C.POINTER(C.c_float), C.c_uint32]),
+    ("rtr_kernel_name", C.c_char_p, [_ctx]),
     ("rtr_selftest_sqrt", C.c_int, [_ctx, C.POINTER(C.c_uint64)]),
     ("rtr_selftest_div", C.c_int, [_ctx, C.c_float, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]),
 ]

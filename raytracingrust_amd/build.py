@@ -29,6 +29,19 @@ FLAGS = [
 ]
 
 
+def kernel_sha() -> str:
+    """Hash of everything that decides the device code: kernel sources, shared headers, launcher and compiler flags.
+    rocprofv3 summaries under profiles/ carry it; bench.py reports their counters only while it still matches."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for name in ("rtr_kernels.hip", "rtr_device.h", "rtr_api.cpp"):
+        with open(os.path.join(CSRC, name), "rb") as fh:
+            h.update(fh.read())
+    h.update(" ".join(FLAGS).encode())
+    return h.hexdigest()[:16]
+
+
 def _hipcc() -> str:
     for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
         if cand and os.path.exists(cand):

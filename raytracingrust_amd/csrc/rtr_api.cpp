@@ -25,9 +25,11 @@ hipError_t launch_resolve(const float *sum_rgba, uint32_t spp, uint32_t n_pixels
                           hipStream_t stream);
 hipError_t render_kernel_attributes(const RenderParams &p, int *vgprs, int *static_lds);
 uint32_t render_resident_waves(const RenderParams &p, uint32_t lds_bytes);
+const char *render_kernel_name(const RenderParams &p);
 hipError_t launch_sum_samples(const float *samples, uint32_t n_samples, float *acc_io, bool first_batch, bool last_batch, uint32_t spp,
                               uint32_t n_pixels, float *sum_rgba, uint8_t *rgba8, float *mean_rgb, hipStream_t stream);
 hipError_t launch_selftest_sqrt(unsigned long long *d_mismatches, hipStream_t stream);
+hipError_t launch_debug_fault(unsigned long long *fault, hipStream_t stream);
 hipError_t launch_selftest_div(float d, uint32_t lo_bits, uint32_t hi_bits, unsigned long long *d_mismatches, hipStream_t stream);
 } // namespace rtr
 
@@ -50,10 +52,11 @@ struct rtr_context {
     rtr::BuildOptions build_options;
     int tree_kernel = 0; // option "tree_kernel": 0 auto, 1 resumable, 2 wave
     int sample_chunks = 0; // option "sample_chunks": 0 auto, else the number of pieces
+    double chunk_timeout_s = 10.0; // option "chunk_timeout_ms": bound of a sample chunk's wait for its predecessor
+    bool debug_fault = false;      // option "debug_fault": the next launches set bit 1 of the fault word
     void *d_samples = nullptr; // k_render_bvh_sp: one float4 per (sample, pixel) of a launch
     uint32_t samples_batch = 0;  // option "samples_batch": samples per batch of that buffer (0: as many as 16 GiB hold)
     size_t samples_cap = 0;
-    uint32_t last_chunks = 1, last_tiles_launch = 0; // of the most recent launch
     void *d_carry = nullptr;       // float4 per pixel: running sums between sample chunks
     size_t carry_cap = 0;
     void *d_chunk_flags = nullptr; // per tile + 1
@@ -67,10 +70,11 @@ struct rtr_context {
     uint64_t device_bytes = 0;
     double upload_ms = 0.0;
     // per-launch bookkeeping
-    hipEvent_t ev_start[kRing] = {}, ev_stop[kRing] = {};
+    hipEvent_t ev_start[kRing] = {}, ev_stop[kRing] = {}, ev_mid[kRing] = {}; // mid: after the launch's last integrate kernel
+    std::string kernel_name; // of the most recent launch's integrate kernel
     hipEvent_t ev_res_start = nullptr, ev_res_stop = nullptr;
     bool resolve_timed = false;
-    unsigned long long *d_counters = nullptr; // kRing slots
+    unsigned long long *d_counters = nullptr; // kRing slots + the sticky fault word (slot kRing)
     uint32_t launches = 0;
     uint64_t last_primary = 0;
     uint32_t last_lds = 0, last_vgprs = 0;
@@ -115,6 +119,19 @@ int upload_vec(rtr_context *ctx, const std::vector<T> &v, void **dst) {
     return RTR_OK;
 }
 
+// The random streams are keyed by (seed, pixel, sample) (rtr_kernels.hip).  Both halves of the seed go through a hash
+// into BOTH keys, so that two seeds never give frames that are pixel permutations of each other (with a plain
+// `pixel ^ seed_lo` the streams of (pixel p, seed s) and (pixel p ^ d, seed s ^ d) coincide).
+uint32_t hash32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+    return x;
+}
+void seed_keys(uint64_t seed, uint32_t &key0, uint32_t &key1) {
+    const uint32_t lo = (uint32_t)seed, hi = (uint32_t)(seed >> 32);
+    key0 = hash32(lo ^ hash32(hi + 0x9E3779B9u));
+    key1 = hash32(hi ^ hash32(lo + 0x85EBCA6Bu));
+}
+
 int check_settings(rtr_context *ctx, const rtr_camera *camera, const rtr_settings *st, uint32_t width, uint32_t height) {
     if (!camera || !st) return fail(ctx, RTR_ERR_INVALID_ARGUMENT, "null camera or settings");
     if (width == 0 || height == 0) return fail(ctx, RTR_ERR_BAD_SETTINGS, "empty render target");
@@ -124,6 +141,19 @@ int check_settings(rtr_context *ctx, const rtr_camera *camera, const rtr_setting
         return fail(ctx, RTR_ERR_BAD_SETTINGS, "clamp_indirect NaN or negative: f32::clamp panics (render.rs:95)");
     if (st->mode > RTR_MODE_NORMAL) return fail(ctx, RTR_ERR_BAD_SETTINGS, "unknown render mode");
     return RTR_OK;
+}
+
+// The device's sticky fault word (rtr_device.h RenderParams::fault), read where the API has just synchronised.
+// A set bit fails the call and is cleared, so one bad launch fails exactly one call.
+int check_fault(rtr_context *ctx) {
+    unsigned long long word = 0;
+    RTR_HIP_TRY(ctx, hipMemcpy(&word, ctx->d_counters + kRing, sizeof word, hipMemcpyDeviceToHost));
+    if (!word) return RTR_OK;
+    RTR_HIP_TRY(ctx, hipMemset(ctx->d_counters + kRing, 0, sizeof word));
+    if (word & 1ull)
+        return fail(ctx, RTR_ERR_HIP, "a sample chunk timed out waiting for its predecessor: the frames rendered since the last "
+                                      "synchronising call are invalid");
+    return fail(ctx, RTR_ERR_HIP, "device fault word set by the debug_fault option");
 }
 
 int ensure_scratch(rtr_context *ctx, void **buf, size_t *cap, size_t need) {
@@ -161,7 +191,7 @@ int launch_frame(rtr_context *ctx, const rtr_camera *camera, const rtr_settings 
         return fail(ctx, RTR_ERR_INVALID_ARGUMENT, "sample range exceeds samples_per_pixel");
     p.sample_begin = sample_begin; p.sample_count = sample_count;
     p.clamp_indirect = st->clamp_indirect;
-    p.seed_lo = (uint32_t)seed; p.seed_hi = (uint32_t)(seed >> 32);
+    seed_keys(seed, p.seed_key0, p.seed_key1);
     // render.rs:68-72: the tree when enable_bvh_tree, else the linear scan of scene.rs:141-157
     if (st->enable_bvh_tree) { p.world = rtr::WORLD_BVH; p.stack_cap = fs.stack_depth + 1u; }
     else if (fs.spheres_only) { p.world = rtr::WORLD_LINEAR_SPHERES; p.stack_cap = 0u; }
@@ -203,6 +233,8 @@ int launch_frame(rtr_context *ctx, const rtr_camera *camera, const rtr_settings 
     p.sum_rgba = d_sum_rgba; p.rgba8 = d_rgba8; p.mean_rgb = d_mean_rgb;
     const uint32_t slot = ctx->launches % kRing;
     p.counter = ctx->d_counters + slot;
+    p.fault = ctx->d_counters + kRing;
+    p.chunk_timeout_ticks = (unsigned long long)(ctx->chunk_timeout_s * 1.0e8); // s_memrealtime counts at 100 MHz
 
     uint32_t grid = p.tiles_total > shard ? (p.tiles_total - shard + n_shards - 1u) / n_shards : 0u;
     // small tables staged in LDS: the linear sphere world's records, and the materials when they fit 4 KB
@@ -256,7 +288,6 @@ int launch_frame(rtr_context *ctx, const rtr_camera *camera, const rtr_settings 
         p.chunks = want;
         p.chunk_taper = p.world == rtr::WORLD_LINEAR_SPHERES ? 6u : 0u; // see chunk_boundary
     }
-    ctx->last_chunks = p.sample_parallel ? 1u : p.chunks; ctx->last_tiles_launch = grid;
     // k_render_bvh_sp's sample buffer: sample_count * W * H float4, in batches of at most 16 GiB (1080p: 512 samples)
     uint32_t batch_samples = sample_count;
     if (p.sample_parallel) {
@@ -273,14 +304,16 @@ int launch_frame(rtr_context *ctx, const rtr_camera *camera, const rtr_settings 
     if (p.chunks > 1u && !p.sample_parallel) {
         int rc = ensure_scratch(ctx, &ctx->d_carry, &ctx->carry_cap, (size_t)width * height * 4u * sizeof(float));
         if (rc) return rc;
-        if ((rc = ensure_scratch(ctx, &ctx->d_chunk_flags, &ctx->chunk_flags_cap, ((size_t)grid + 1u) * sizeof(uint32_t)))) return rc;
+        if ((rc = ensure_scratch(ctx, &ctx->d_chunk_flags, &ctx->chunk_flags_cap, (size_t)grid * sizeof(uint32_t)))) return rc;
         p.carry_rgba = static_cast<float *>(ctx->d_carry);
         p.chunk_flags = static_cast<uint32_t *>(ctx->d_chunk_flags);
-        RTR_HIP_TRY(ctx, hipMemsetAsync(ctx->d_chunk_flags, 0, ((size_t)grid + 1u) * sizeof(uint32_t), stream));
+        RTR_HIP_TRY(ctx, hipMemsetAsync(ctx->d_chunk_flags, 0, (size_t)grid * sizeof(uint32_t), stream));
     }
     RTR_HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters + slot, 0, sizeof(unsigned long long), stream));
     RTR_HIP_TRY(ctx, hipEventRecord(ctx->ev_start[slot], stream));
     if (grid > 0 && !p.sample_parallel) RTR_HIP_TRY(ctx, rtr::launch_render(p, grid * p.chunks, lds_bytes, stream));
+    if (!p.sample_parallel) RTR_HIP_TRY(ctx, hipEventRecord(ctx->ev_mid[slot], stream));
+    if (grid == 0 && p.sample_parallel) RTR_HIP_TRY(ctx, hipEventRecord(ctx->ev_mid[slot], stream));
     if (grid > 0 && p.sample_parallel) {
         // batch by batch: render the batch's samples, then add them to each pixel's sum in index order; the last
         // batch's k_sum_samples finishes the pixel (or stores the launch's partial sum)
@@ -291,16 +324,19 @@ int launch_frame(rtr_context *ctx, const rtr_camera *camera, const rtr_settings 
             b.chunks = std::max(1u, std::min(p.chunks, b.sample_count));
             const bool first = done == 0u, last = done + b.sample_count == sample_count;
             RTR_HIP_TRY(ctx, rtr::launch_render(b, grid * b.chunks, lds_bytes, stream));
+            if (last) RTR_HIP_TRY(ctx, hipEventRecord(ctx->ev_mid[slot], stream));
             RTR_HIP_TRY(ctx, rtr::launch_sum_samples(p.samples, b.sample_count, static_cast<float *>(ctx->d_carry), first, last, p.spp,
                                                      width * height, d_sum_rgba, d_rgba8, d_mean_rgb, stream));
         }
     }
+    if (ctx->debug_fault) RTR_HIP_TRY(ctx, rtr::launch_debug_fault(p.fault, stream));
     RTR_HIP_TRY(ctx, hipEventRecord(ctx->ev_stop[slot], stream));
     ctx->launches++;
     {
         int vg = 0, sl = 0;
         if (rtr::render_kernel_attributes(p, &vg, &sl) == hipSuccess) ctx->last_vgprs = (uint32_t)vg;
     }
+    ctx->kernel_name = rtr::render_kernel_name(p);
     return RTR_OK;
 }
 
@@ -340,11 +376,12 @@ int rtr_create(int device, rtr_context **out) {
     for (int i = 0; i < kRing; i++) {
         if ((e = hipEventCreate(&ctx->ev_start[i])) != hipSuccess) return bail(e, "hipEventCreate");
         if ((e = hipEventCreate(&ctx->ev_stop[i])) != hipSuccess) return bail(e, "hipEventCreate");
+        if ((e = hipEventCreate(&ctx->ev_mid[i])) != hipSuccess) return bail(e, "hipEventCreate");
     }
     if ((e = hipEventCreate(&ctx->ev_res_start)) != hipSuccess) return bail(e, "hipEventCreate");
     if ((e = hipEventCreate(&ctx->ev_res_stop)) != hipSuccess) return bail(e, "hipEventCreate");
-    if ((e = hipMalloc((void **)&ctx->d_counters, kRing * sizeof(unsigned long long))) != hipSuccess) return bail(e, "hipMalloc");
-    if ((e = hipMemset(ctx->d_counters, 0, kRing * sizeof(unsigned long long))) != hipSuccess) return bail(e, "hipMemset");
+    if ((e = hipMalloc((void **)&ctx->d_counters, (kRing + 1) * sizeof(unsigned long long))) != hipSuccess) return bail(e, "hipMalloc");
+    if ((e = hipMemset(ctx->d_counters, 0, (kRing + 1) * sizeof(unsigned long long))) != hipSuccess) return bail(e, "hipMemset");
     *out = ctx;
     return RTR_OK;
 }
@@ -358,6 +395,7 @@ void rtr_destroy(rtr_context *ctx) {
         for (int i = 0; i < kRing; i++) {
             if (ctx->ev_start[i]) (void)hipEventDestroy(ctx->ev_start[i]);
             if (ctx->ev_stop[i]) (void)hipEventDestroy(ctx->ev_stop[i]);
+            if (ctx->ev_mid[i]) (void)hipEventDestroy(ctx->ev_mid[i]);
         }
         if (ctx->ev_res_start) (void)hipEventDestroy(ctx->ev_res_start);
         if (ctx->ev_res_stop) (void)hipEventDestroy(ctx->ev_res_stop);
@@ -440,6 +478,19 @@ int rtr_set_option(rtr_context *ctx, const char *name, const char *value) {
         const unsigned long k = std::strtoul(v.c_str(), &end, 10);
         if (v.empty() || *end != '\0' || k < 1ul || k > 4096ul) return fail(ctx, RTR_ERR_INVALID_ARGUMENT, "sample_chunks must be \"auto\" or an integer in [1, 4096]");
         ctx->sample_chunks = (int)k;
+        return RTR_OK;
+    }
+    if (n == "chunk_timeout_ms") { // takes effect at the next render
+        char *end = nullptr;
+        const double ms = std::strtod(v.c_str(), &end);
+        if (v.empty() || *end != '\0' || !(ms >= 0.0) || ms > 6.0e5) return fail(ctx, RTR_ERR_INVALID_ARGUMENT, "chunk_timeout_ms must be a number in [0, 600000]");
+        ctx->chunk_timeout_s = ms * 1.0e-3;
+        return RTR_OK;
+    }
+    if (n == "debug_fault") { // testing aid: the following launches set the fault word
+        if (v == "on") ctx->debug_fault = true;
+        else if (v == "off") ctx->debug_fault = false;
+        else return fail(ctx, RTR_ERR_INVALID_ARGUMENT, "debug_fault must be \"on\" or \"off\"");
         return RTR_OK;
     }
     if (n == "leaf_pairs") {
@@ -542,12 +593,7 @@ int rtr_render(rtr_context *ctx, const rtr_camera *camera, const rtr_settings *s
     if (rgba8) RTR_HIP_TRY(ctx, hipMemcpyAsync(rgba8, d8, npx * 4, hipMemcpyDeviceToHost, ctx->stream));
     if (mean_rgb) RTR_HIP_TRY(ctx, hipMemcpyAsync(mean_rgb, dm, npx * 3 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     RTR_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    if (ctx->last_chunks > 1u) { // a sample chunk that gave up waiting for its predecessor (never expected)
-        uint32_t timed_out = 0;
-        RTR_HIP_TRY(ctx, hipMemcpy(&timed_out, static_cast<uint32_t *>(ctx->d_chunk_flags) + ctx->last_tiles_launch, sizeof timed_out, hipMemcpyDeviceToHost));
-        if (timed_out) return fail(ctx, RTR_ERR_HIP, "a sample chunk timed out waiting for its predecessor (internal error)");
-    }
-    return RTR_OK;
+    return check_fault(ctx);
 }
 
 int rtr_render_rgba8(rtr_context *ctx, const rtr_camera *camera, const rtr_settings *settings, uint32_t width,
@@ -577,6 +623,7 @@ int rtr_get_stats(rtr_context *ctx, rtr_stats *out) {
     if (ctx->device < 0 || ctx->launches == 0) return RTR_OK;
     RTR_HIP_TRY(ctx, hipSetDevice(ctx->device));
     RTR_HIP_TRY(ctx, hipDeviceSynchronize());
+    if (int rc = check_fault(ctx)) return rc;
     uint32_t slot = (ctx->launches - 1u) % kRing;
     float ms = 0.0f;
     RTR_HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev_start[slot], ctx->ev_stop[slot]));
@@ -597,6 +644,7 @@ int rtr_kernel_times_ms(rtr_context *ctx, float *out, uint32_t cap) {
     if (ctx->device < 0 || ctx->launches == 0) return 0;
     RTR_HIP_TRY(ctx, hipSetDevice(ctx->device));
     RTR_HIP_TRY(ctx, hipDeviceSynchronize());
+    if (int rc = check_fault(ctx)) return rc;
     uint32_t n = ctx->launches < (uint32_t)kRing ? ctx->launches : (uint32_t)kRing;
     if (n > cap) n = cap;
     for (uint32_t i = 0; i < n; i++) {
@@ -606,6 +654,30 @@ int rtr_kernel_times_ms(rtr_context *ctx, float *out, uint32_t cap) {
         out[i] = ms;
     }
     return (int)n;
+}
+
+int rtr_integrate_times_ms(rtr_context *ctx, float *out, uint32_t cap) {
+    if (!ctx || !out) return RTR_ERR_INVALID_ARGUMENT;
+    RTR_LOCK(ctx);
+    if (ctx->device < 0 || ctx->launches == 0) return 0;
+    RTR_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    RTR_HIP_TRY(ctx, hipDeviceSynchronize());
+    if (int rc = check_fault(ctx)) return rc;
+    uint32_t n = ctx->launches < (uint32_t)kRing ? ctx->launches : (uint32_t)kRing;
+    if (n > cap) n = cap;
+    for (uint32_t i = 0; i < n; i++) {
+        uint32_t slot = (ctx->launches - n + i) % kRing;
+        float ms = 0.0f;
+        RTR_HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev_start[slot], ctx->ev_mid[slot]));
+        out[i] = ms;
+    }
+    return (int)n;
+}
+
+const char *rtr_kernel_name(const rtr_context *ctx) {
+    if (!ctx) return "";
+    RTR_LOCK(ctx);
+    return ctx->kernel_name.c_str();
 }
 
 int rtr_selftest_sqrt(rtr_context *ctx, uint64_t *mismatches) {
@@ -643,6 +715,7 @@ int rtr_segment_counts(rtr_context *ctx, uint64_t *out, uint32_t cap) {
     if (ctx->device < 0 || ctx->launches == 0) return 0;
     RTR_HIP_TRY(ctx, hipSetDevice(ctx->device));
     RTR_HIP_TRY(ctx, hipDeviceSynchronize());
+    if (int rc = check_fault(ctx)) return rc;
     uint32_t n = ctx->launches < (uint32_t)kRing ? ctx->launches : (uint32_t)kRing;
     if (n > cap) n = cap;
     unsigned long long ring[kRing];

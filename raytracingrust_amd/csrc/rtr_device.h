@@ -88,7 +88,7 @@ struct RenderParams {
     uint32_t spp, max_depth, mode;   // spp: the frame's samples per pixel (the divisor of the fused resolve)
     uint32_t sample_begin, sample_count; // the samples this launch integrates (whole frame: 0, spp)
     float clamp_indirect;
-    uint32_t seed_lo, seed_hi;
+    uint32_t seed_key0, seed_key1; // two 32-bit hashes of the 64-bit seed (rtr_api.cpp seed_keys; the oracle's or_rng_seed)
     // world
     uint32_t world, n_objects;
     uint32_t root_ref;
@@ -119,7 +119,9 @@ struct RenderParams {
     uint32_t chunk_taper;   // 0: equal pieces; k in 1..7: lengths fall linearly from (8+k)/8 to (8-k)/8 of the mean
     float *carry_rgba;      // float4 running sums handed from chunk to chunk (chunks > 1)
     float *samples;         // k_render_bvh_sp: float4 [sample - sample_begin][pixel], one clamped radiance per sample
-    uint32_t *chunk_flags;  // per launch-local tile: chunks completed; [tiles_launch] = timeout flag (chunks > 1)
+    uint32_t *chunk_flags;  // per launch-local tile: chunks completed (chunks > 1)
+    unsigned long long chunk_timeout_ticks; // bound of a chunk's wait for its predecessor, in s_memrealtime ticks (100 MHz)
+    unsigned long long *fault; // the context's sticky fault word: bit 0 = a chunk gave up waiting, bit 1 = "debug_fault"
     // outputs
     float *sum_rgba;             // float4 per pixel (sharded path) or nullptr
     uint8_t *rgba8;              // fused path or nullptr

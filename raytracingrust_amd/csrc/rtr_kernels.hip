@@ -24,6 +24,16 @@ namespace rtr {
 
 #define RTR_DEV __device__ __forceinline__
 
+#ifdef RTR_X_LANESTAT // diagnostic build only (scripts/lanestat.py): lanes active per block of the headline kernel's loop
+__shared__ uint32_t rtr_lsc[32];
+#define RTR_LS(k, cond) { const uint64_t m_ = __ballot(cond); \
+        if (m_ && lane == (uint32_t)(__ffsll((long long)m_) - 1)) atomicAdd(&rtr_lsc[k], (uint32_t)__popcll(m_)); }
+#define RTR_LS1(k) { const uint64_t m_ = __ballot(true); if (lane == (uint32_t)(__ffsll((long long)m_) - 1)) atomicAdd(&rtr_lsc[k], 1u); }
+#else
+#define RTR_LS(k, cond)
+#define RTR_LS1(k)
+#endif
+
 struct V3 { float x, y, z; };
 RTR_DEV V3 mk(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
 RTR_DEV V3 ld3(const float *p) { return mk(p[0], p[1], p[2]); }
@@ -82,15 +92,26 @@ RTR_DEV uint32_t rng_u32(Rng &r) {
 RTR_DEV float rng_value01(Rng &r) { return __uint_as_float(0x3f800000u | (rng_u32(r) >> 9)) - 1.0f; }
 RTR_DEV float rng_unit_inclusive(Rng &r) { return rng_value01(r) * 0x1.000002p+0f; } // Uniform::from(0.0..=1.0), render.rs:81
 RTR_DEV float rng_unit(Rng &r) { return rng_value01(r); }                            // gen_range(0.0..1.0), materials.rs:127,151
-RTR_DEV float rng_signed(Rng &r) { return __uint_as_float(0x40000000u | (rng_u32(r) >> 9)) - 3.0f; } // gen_range(-1.0..1.0), sample.rs:29-31
 
-// sample.rs:43-51 rejection-sampled unit ball; returns |v|^2 through m2
+// sample.rs:43-51 rejection-sampled unit ball; returns |v|^2 through m2.  The candidates of ONE call come from a
+// sub-stream of their own: one word r of the path's stream seeds a plain 32-bit LCG (the PCG multiplier, a fixed odd
+// increment) whose successive states give x, y, z of candidate 0, 1, 2, ... through their top 23 bits -- rand 0.8's
+// gen_range(-1.0..1.0) grid, as before.  The path's stream therefore advances by exactly one word per call however
+// many candidates are rejected, candidate k is a closed-form function of (r, k) (LCG jump-ahead), and a candidate
+// costs three multiply-adds instead of three PCG output permutations: the rejection loop is the most divergent block
+// of the headline kernel (11 of 64 lanes active per wave iteration, scripts/lanestat.py).
+constexpr uint32_t kBallMul = 747796405u, kBallInc = 2891336453u;
+RTR_DEV float ball_coord(uint32_t &s) {
+    s = s * kBallMul + kBallInc;
+    return __uint_as_float(__builtin_amdgcn_alignbit(0x80u, s, 9u)) - 3.0f; // 0x40000000 | (s >> 9): [2, 4) - 3
+}
 RTR_DEV V3 sample_unit_ball(Rng &rng, float &m2) {
+    uint32_t s = rng_u32(rng);
     V3 v;
     do {
-        v.x = rng_signed(rng);
-        v.y = rng_signed(rng);
-        v.z = rng_signed(rng);
+        v.x = ball_coord(s);
+        v.y = ball_coord(s);
+        v.z = ball_coord(s);
         m2 = dot(v, v);
     } while (!(m2 <= 1.0f));
     return v;
@@ -532,6 +553,7 @@ RTR_DEV bool world_hit(const RenderParams &p, const Ray &r, Hit &h, uint32_t *st
                 float cc = dot(oc, oc) - sr.r2[i];
                 float disc = half_b * half_b - a * cc;
                 if (!(disc < 0.0f)) { // objects.rs:31-33 (a NaN discriminant goes on, as in the reference)
+                    RTR_LS(2 + i, true) RTR_LS1(7 + i)
                     const float sq = rt_sqrt(disc);
                     const float n1 = -half_b - sq, n2 = -half_b + sq;
                     float n_acc = n1;
@@ -560,6 +582,7 @@ RTR_DEV bool world_hit(const RenderParams &p, const Ray &r, Hit &h, uint32_t *st
 #ifdef RTR_X_COUNT_AMB // diagnostic build only: the segment counter counts exact-path repeats instead
             if (amb) atomicAdd(p.counter, 0x100000000ull);
 #endif
+            RTR_LS(25, amb)
             if (!amb) {
                 if (best >= 0) closest = nb / a;
             } else {
@@ -586,6 +609,7 @@ RTR_DEV bool world_hit(const RenderParams &p, const Ray &r, Hit &h, uint32_t *st
         }
 #endif
         if (best < 0) return false;
+        RTR_LS(12, true)
         const float4 w = *reinterpret_cast<const float4 *>(lds_spheres + best * 8); // centre, radius
         h.material = lds_spheres[best * 8 + 5];
         h.point = add(r.o, scale(r.d, closest));
@@ -741,6 +765,7 @@ RTR_DEV V3 background(const RenderParams &p, const Ray &r) {
 // NaN (render.rs:95-97): the radiance one finished sample adds to its pixel
 RTR_DEV V3 sample_radiance(const RenderParams &p, const uint32_t *lds_mats, const uint32_t *chain, uint32_t lane, uint32_t &nchain, V3 term) {
     while (nchain > 0u) {
+        RTR_LS(24, true) RTR_LS1(23)
         nchain--;
         term = mul(material_rgb(p, lds_mats, chain[nchain * 64u + lane]), term);
     }
@@ -759,6 +784,7 @@ RTR_DEV V3 sample_radiance(const RenderParams &p, const uint32_t *lds_mats, cons
 RTR_DEV bool shade_segment(const RenderParams &p, bool was_hit, const Hit &h, Ray &ray, Rng &rng, const uint32_t *lds_mats,
                            uint32_t *chain, uint32_t lane, uint32_t &nchain, uint32_t &depth, V3 &term) {
     bool done;
+    RTR_LS(17, !was_hit)
     if (!was_hit) {
         term = background(p, ray);
         done = true;
@@ -793,9 +819,20 @@ RTR_DEV bool shade_segment(const RenderParams &p, bool was_hit, const Hit &h, Ra
         // (sample.rs:43-51) and it is their first draw after the mix walk, so the loop is run ONCE for all
         // three kinds (one divergent loop per segment instead of one per material kind).
         V3 sv = mk(0.0f, 0.0f, 0.0f);
+        RTR_LS(13, kind == 0u) RTR_LS(14, kind == 1u) RTR_LS(15, kind == 2u) RTR_LS(16, kind == 3u)
         if (kind == 0u || kind == 1u || kind == 5u) {
             float m2;
+#ifdef RTR_X_LANESTAT
+            RTR_LS1(20)
+            uint32_t bs = rng_u32(rng);
+            do {
+                RTR_LS(19, true) RTR_LS1(18)
+                sv.x = ball_coord(bs); sv.y = ball_coord(bs); sv.z = ball_coord(bs);
+                m2 = dot(sv, sv);
+            } while (!(m2 <= 1.0f));
+#else
             sv = sample_unit_ball(rng, m2);
+#endif
             if (kind != 5u) sv = scale(sv, 1.0f / rt_sqrt(m2)); // sample_unit_sphere_surface, sample.rs:66-70
         }
         if (kind == 0u) { // Lambertian, materials.rs:31-41
@@ -853,8 +890,9 @@ RTR_DEV bool shade_segment(const RenderParams &p, bool was_hit, const Hit &h, Ra
 // draining).  Chunk c of a tile starts from the running sums chunk c-1 left in p.carry_rgba and adds its samples
 // in the same order, so every pixel sees exactly the additions of the unchunked loop: bit-identical.  The hand-over is
 // a per-tile counter: written with release, read with acquire (agent scope).  A workgroup of chunk c is dispatched a
-// whole chunk's worth of workgroups after its predecessor, so the wait is normally over before it starts; it is
-// bounded all the same, and a timeout is reported through the word behind the last tile's counter.
+// whole chunk's worth of workgroups after its predecessor, so the wait is normally over before it starts.  HIP does not
+// promise dispatch order, so the wait is bounded (seconds of wall time) and a timeout sets the context's fault word:
+// every entry point that synchronises then fails with RTR_ERR_HIP instead of handing out a frame built on stale sums.
 // First sample (relative) of chunk c of n.  With taper k (0..7) the chunk lengths fall linearly from (8+k)/8 of the mean
 // to (8-k)/8: what is left running when the launch has no more workgroups to start are pieces of the LAST chunk, so that
 // one should be the smallest.  1080p headline: equal chunks 16.85 ms, k = 2: 16.6, 4: 16.4, 6: 16.2, 7: 16.0-16.1
@@ -869,11 +907,14 @@ RTR_DEV uint32_t chunk_boundary(uint32_t count, uint32_t c, uint32_t n, uint32_t
 }
 
 RTR_DEV void chunk_wait(const RenderParams &p, uint32_t tidx, uint32_t chunk) {
-    uint32_t spins = 0;
+    // Bounded by wall time (s_memrealtime: 100 MHz, independent of the shader clock): a predecessor lives for a
+    // fraction of one launch, the bound is seconds.  Giving up sets bit 0 of the context's sticky fault word, which
+    // every synchronising entry point of the C ABI turns into RTR_ERR_HIP (rtr_api.cpp check_fault).
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     while (__hip_atomic_load(p.chunk_flags + tidx, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < chunk) {
         __builtin_amdgcn_s_sleep(16);
-        if (++spins > (1u << 28)) { // ~2 minutes: far beyond any predecessor's lifetime; give up rather than hang the GPU
-            __hip_atomic_store(p.chunk_flags + p.tiles_launch, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (__builtin_amdgcn_s_memrealtime() - t0 > p.chunk_timeout_ticks) {
+            if (threadIdx.x == 0) atomicOr(p.fault, 1ull);
             break;
         }
     }
@@ -900,6 +941,11 @@ __global__ __launch_bounds__(64, RTR_X_WAVES_PER_EU) void k_render(const RenderP
     const uint32_t chunk = blockIdx.x / p.tiles_launch, tidx = blockIdx.x - chunk * p.tiles_launch;
     const uint32_t tile = tidx * p.n_shards + p.shard;
     if (tile >= p.tiles_total) return;
+#ifdef RTR_X_LANESTAT
+    if (lane < 32u) rtr_lsc[lane] = 0u;
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+#endif
     uint32_t *chain = lds;
     uint32_t *stk_ref = lds + p.max_depth * 64u;
     float *stk_t = reinterpret_cast<float *>(stk_ref + p.stack_cap * 64u);
@@ -937,9 +983,9 @@ __global__ __launch_bounds__(64, RTR_X_WAVES_PER_EU) void k_render(const RenderP
     const V3 cam_o = ld3(p.cam_origin), cam_h = ld3(p.cam_horizontal), cam_v = ld3(p.cam_vertical), cam_llc = ld3(p.cam_llc);
 
     // per-pixel stream constants
-    const uint32_t hp = hash32(pixel ^ p.seed_lo);
+    const uint32_t hp = hash32(pixel ^ p.seed_key0); // the two keys are hashes of the whole 64-bit seed (rtr_api.cpp)
     Rng rng;
-    rng.inc = (hash32(hp + p.seed_hi) << 1) | 1u;
+    rng.inc = (hash32(hp + p.seed_key1) << 1) | 1u;
     rng.state = 0u;
 
     V3 acc = mk(0.0f, 0.0f, 0.0f);
@@ -1001,6 +1047,7 @@ __global__ __launch_bounds__(64, RTR_X_WAVES_PER_EU) void k_render(const RenderP
 #endif
     while (s < spp) {
         RTR_STAMP(4)
+        RTR_LS(1, true) RTR_LS1(0)
         // ---- trace_ray body (render.rs:32-59): one segment ----
         Hit h;
         nseg++;
@@ -1013,7 +1060,9 @@ __global__ __launch_bounds__(64, RTR_X_WAVES_PER_EU) void k_render(const RenderP
         RTR_STAMP(0)
         done = shade_segment(p, was_hit, h, ray, rng, lds_mats, chain, lane, nchain, depth, term);
         RTR_STAMP(1)
+        RTR_LS(21, done)
         if (done) {
+            RTR_LS1(22)
             acc = add(acc, sample_radiance(p, lds_mats, chain, lane, nchain, term)); // render.rs:99
             s++;
             if (s < spp) start_sample(s);
@@ -1023,6 +1072,12 @@ __global__ __launch_bounds__(64, RTR_X_WAVES_PER_EU) void k_render(const RenderP
 #ifdef RTR_X_STAMPS
     if (lane == 0 && p.spp > 1u) // scripts/stamps.py makes 5 one-sample launches first, so slots counter-1..-5 exist
         for (int k = 0; k < 5; k++) atomicAdd(p.counter - 1 - k, st_acc[k]);
+#endif
+#ifdef RTR_X_LANESTAT
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+    if (lane < 32u && p.spp > 1u) // scripts/lanestat.py makes 32 one-sample launches first, so slots counter-1..-32 exist
+        atomicAdd(p.counter - 1 - lane, (unsigned long long)rtr_lsc[lane]);
 #endif
 
     if (chunk + 1u < p.chunks) {
@@ -1109,9 +1164,9 @@ __global__ __launch_bounds__(64, RTR_X_BVH_WAVES) void k_render_bvh(const Render
     const uint32_t pixel = y * p.width + x;
     const float fx = (float)x, fy = (float)y;
     const V3 cam_o = ld3(p.cam_origin), cam_h = ld3(p.cam_horizontal), cam_v = ld3(p.cam_vertical), cam_llc = ld3(p.cam_llc);
-    const uint32_t hp = hash32(pixel ^ p.seed_lo);
+    const uint32_t hp = hash32(pixel ^ p.seed_key0); // the two keys are hashes of the whole 64-bit seed (rtr_api.cpp)
     Rng rng;
-    rng.inc = (hash32(hp + p.seed_hi) << 1) | 1u;
+    rng.inc = (hash32(hp + p.seed_key1) << 1) | 1u;
     rng.state = 0u;
 
     V3 acc = mk(0.0f, 0.0f, 0.0f);
@@ -1311,6 +1366,11 @@ __global__ __launch_bounds__(64, 6) void k_render_bvh_sp(const RenderParams p) {
     const uint32_t chunk = blockIdx.x / p.tiles_launch, tidx = blockIdx.x - chunk * p.tiles_launch;
     const uint32_t tile = tidx * p.n_shards + p.shard;
     if (tile >= p.tiles_total) return;
+#ifdef RTR_X_LANESTAT
+    if (lane < 32u) rtr_lsc[lane] = 0u;
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+#endif
     uint32_t *chain = lds;
     uint32_t *stk_ref = lds + p.max_depth * 64u;
     float *stk_t = reinterpret_cast<float *>(stk_ref + p.stack_cap * 64u);
@@ -1394,8 +1454,8 @@ __global__ __launch_bounds__(64, 6) void k_render_bvh_sp(const RenderParams p) {
                     if (x < p.width && y < p.height) { // else: off the ragged edge, ask again
                         const uint32_t pixel = y * p.width + x; // render.rs:76-77
                         fx = (float)x; fy = (float)y;
-                        hp = hash32(pixel ^ p.seed_lo);
-                        rng.inc = (hash32(hp + p.seed_hi) << 1) | 1u;
+                        hp = hash32(pixel ^ p.seed_key0);
+                        rng.inc = (hash32(hp + p.seed_key1) << 1) | 1u;
                         slot = (uint64_t)(si - p.sample_begin) * n_pixels + pixel;
                         need = false;
                         alive = true;
@@ -1412,6 +1472,7 @@ __global__ __launch_bounds__(64, 6) void k_render_bvh_sp(const RenderParams p) {
         const uint64_t alive_mask = __ballot(alive);
         if (alive_mask == 0ull) break;
         const uint32_t quorum = (uint32_t)__popcll(alive_mask) * RTR_TREE_QUORUM_NUM / RTR_TREE_QUORUM_DEN;
+        RTR_LS1(0) RTR_LS(15, alive)
         // ---- walk: one trip per iteration for every lane still walking ----
         // (The trip is `traverse`'s loop body, repeated here on purpose: as one function shared by both callers it
         // compiled 6 ... 18 % slower in either.)
@@ -1422,12 +1483,15 @@ __global__ __launch_bounds__(64, 6) void k_render_bvh_sp(const RenderParams p) {
 #pragma unroll
             for (uint32_t rep = 0; rep < kWalkUnroll; rep++)
             if (walking) {
+                RTR_LS1(1) RTR_LS(2, true)
                 bool pop = false;
                 if (cur & REF_LEAF) {
+                    RTR_LS1(4) RTR_LS(3, true)
                     test_leaf<VOL>(p, cur & ~REF_PAIR, ray, a, best, rng);
                     pop = !(cur & REF_PAIR);
                     cur = (cur & ~REF_PAIR) + 1u;
                 } else {
+                    RTR_LS1(6) RTR_LS(5, true)
                     const float4 *nq = reinterpret_cast<const float4 *>(p.nodes + cur);
                     float4 q0 = nq[0], q1 = nq[1], q2 = nq[2], q3 = nq[3];
                     gather_fence(q0, q1, q2, q3);
@@ -1458,6 +1522,7 @@ __global__ __launch_bounds__(64, 6) void k_render_bvh_sp(const RenderParams p) {
                             if (!rvol && er > best.t) hr = false;
                         }
                     }
+                    RTR_LS(14, hl && hr)
                     if (hl && hr) {
                         bool sw = er < el;
                         if (lvol && rvol) sw = false;
@@ -1477,8 +1542,10 @@ __global__ __launch_bounds__(64, 6) void k_render_bvh_sp(const RenderParams p) {
                     }
                 }
                 if (pop) {
+                    RTR_LS1(8) RTR_LS(7, true)
                     bool got = false;
                     while (sp > 0) {
+                        RTR_LS1(9) RTR_LS(10, true)
                         sp--;
                         uint32_t c = stk_ref[sp * 64 + lane];
                         float e = stk_t[sp * 64 + lane];
@@ -1493,6 +1560,7 @@ __global__ __launch_bounds__(64, 6) void k_render_bvh_sp(const RenderParams p) {
         }
         // ---- the lanes whose walk has ended: the rest of trace_ray, then the next segment or the next sample ----
         if (alive && !walking) {
+            RTR_LS1(11) RTR_LS(12, true)
             Hit h;
             const bool was_hit = best.leaf != REF_NONE;
             if (was_hit) finish_leaf<VOL>(p, best, ray, h);
@@ -1510,6 +1578,11 @@ __global__ __launch_bounds__(64, 6) void k_render_bvh_sp(const RenderParams p) {
         fetch_work();
     }
 
+#ifdef RTR_X_LANESTAT
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+    if (lane < 32u && p.spp > 1u) atomicAdd(p.counter - 1 - lane, (unsigned long long)rtr_lsc[lane]);
+#endif
     unsigned long long total = nseg;
     for (int off = 32; off > 0; off >>= 1) total += __shfl_xor(total, off, 64);
     if (lane == 0 && total) atomicAdd(p.counter, total);
@@ -1597,6 +1670,14 @@ __global__ __launch_bounds__(256) void k_selftest_div(float d, uint32_t lo_bits,
         bad += (__float_as_uint(q) == __float_as_uint(ref)) ? 0u : 1u;
     }
     if (bad) atomicAdd(mismatches, (unsigned long long)bad);
+}
+
+// option "debug_fault": sets bit 1 of the context's fault word, as a chunk that timed out sets bit 0 (tests the
+// path from the device word to the C ABI's error code without a kernel that misbehaves)
+__global__ void k_debug_fault(unsigned long long *fault) { atomicOr(fault, 2ull); }
+hipError_t launch_debug_fault(unsigned long long *fault, hipStream_t stream) {
+    hipLaunchKernelGGL(k_debug_fault, dim3(1), dim3(1), 0, stream, fault);
+    return hipGetLastError();
 }
 
 hipError_t launch_selftest_div(float d, uint32_t lo_bits, uint32_t hi_bits, unsigned long long *d_mismatches, hipStream_t stream) {
@@ -1691,6 +1772,16 @@ hipError_t render_kernel_attributes(const RenderParams &p, int *vgprs, int *stat
     *vgprs = attr.numRegs;
     *static_lds = (int)attr.sharedSizeBytes;
     return hipSuccess;
+}
+
+// the name rocprofv3 prints for the kernel launch_render would take (bench.py's roofline.kernel)
+const char *render_kernel_name(const RenderParams &p) {
+    if (p.world == WORLD_BVH && p.sample_parallel) return "rtr::k_render_bvh_sp (tree world, lanes take samples) + rtr::k_sum_samples";
+    if (p.world == WORLD_BVH && p.resumable_walk) return "rtr::k_render_bvh (tree world, resumable walk)";
+    if (p.world == WORLD_BVH) return "rtr::k_render<WORLD_BVH> (tree world, wave-synchronous walk)";
+    if (p.world == WORLD_LINEAR_GENERIC) return "rtr::k_render<WORLD_LINEAR_GENERIC> (linear world with meshes)";
+    return p.sphere_regs ? "rtr::k_render<WORLD_LINEAR_SPHERES, NS> (linear world, spheres in scalar registers)"
+                         : "rtr::k_render<WORLD_LINEAR_SPHERES, 0> (linear world, generic sphere loop)";
 }
 
 static const void *render_kernel(const RenderParams &p) {

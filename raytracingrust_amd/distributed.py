@@ -70,11 +70,40 @@ def render_frame_distributed(renderer, width: int, height: int, seed: int, accum
     return accum
 
 
+class _NullStream:
+    """Stand-ins for torch.cuda streams / events when the pipeline runs on CPU tensors (gloo tests): every operation is
+    synchronous there, so ordering is program order."""
+    cuda_stream = 0
+
+    def wait_event(self, event):
+        pass
+
+    def synchronize(self):
+        pass
+
+
+class _NullEvent:
+    def record(self, stream=None):
+        pass
+
+
+class _NullContext:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
 class FramePipeline:
     """Double-buffered multi-GPU frames: the RCCL reduce (+ rank 0's resolve) of frame i runs on a communication
     stream while the integrate kernel of frame i+1 runs on the compute stream, so a frame costs
     max(integrate, reduce) instead of their sum.  Two float4 sum buffers alternate; HIP events order
-    zero -> integrate -> reduce -> resolve -> reuse.  Results are identical to `render_frame_distributed`."""
+    zero -> integrate -> reduce -> resolve -> reuse.  Results are identical to `render_frame_distributed`.
+
+    With `device` = "cpu" the same sequence runs on CPU tensors over whatever backend the process group has (gloo in
+    tests/test_distributed_cpu.py, with a stand-in for the two renderer entry points): the sharding, buffer rotation and
+    the collective are the code under test there, the kernels are not."""
 
     def __init__(self, renderer, width: int, height: int, spp: int, device, group=None, split: str = "samples"):
         import torch
@@ -83,12 +112,18 @@ class FramePipeline:
         self.torch, self.dist = torch, dist
         self.r, self.w, self.h, self.spp, self.group = renderer, width, height, spp, group
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        self.on_gpu = torch.device(device).type != "cpu"
         self.accum = [torch.zeros((height, width, 4), dtype=torch.float32, device=device) for _ in range(2)]
         self.rgba8 = torch.zeros((height, width, 4), dtype=torch.uint8, device=device) if self.rank == 0 else None
-        self.compute = torch.cuda.Stream(device=device)
-        self.comm = torch.cuda.Stream(device=device)
-        self.rendered = [torch.cuda.Event() for _ in range(2)]
-        self.free = [torch.cuda.Event() for _ in range(2)]
+        if self.on_gpu:
+            self.compute = torch.cuda.Stream(device=device)
+            self.comm = torch.cuda.Stream(device=device)
+            self.rendered = [torch.cuda.Event() for _ in range(2)]
+            self.free = [torch.cuda.Event() for _ in range(2)]
+        else:
+            self.compute, self.comm = _NullStream(), _NullStream()
+            self.rendered = [_NullEvent() for _ in range(2)]
+            self.free = [_NullEvent() for _ in range(2)]
         # "samples": every rank integrates ALL pixels for its contiguous share of the samples -- each GPU keeps a
         # full grid of (shorter) waves, so the per-GPU kernel time scales 1/N; the reduce is a true sum of partial
         # sums (float addition order differs from one GPU: ~1e-7 relative).  "tiles": round-robin 8x8 tiles, all
@@ -98,12 +133,16 @@ class FramePipeline:
             raise ValueError("split must be 'samples' or 'tiles'")
         self.split = split if spp >= self.world else "tiles"
         self.n = 0
-        torch.cuda.synchronize(device)
+        if self.on_gpu:
+            torch.cuda.synchronize(device)
+
+    def _on(self, stream):
+        return self.torch.cuda.stream(stream) if self.on_gpu else _NullContext()
 
     def submit(self, seed: int) -> None:
-        torch, dist = self.torch, self.dist
+        dist = self.dist
         b = self.n % 2
-        with torch.cuda.stream(self.compute):
+        with self._on(self.compute):
             if self.n >= 2:
                 self.compute.wait_event(self.free[b])  # frame n-2 has left this buffer
             if self.split == "tiles":
@@ -115,7 +154,7 @@ class FramePipeline:
                 self.r.render_samples_device(self.w, self.h, seed, begin, count, self.accum[b].data_ptr(),
                                              self.compute.cuda_stream)
             self.rendered[b].record(self.compute)
-        with torch.cuda.stream(self.comm):
+        with self._on(self.comm):
             self.comm.wait_event(self.rendered[b])
             dist.reduce(self.accum[b], dst=0, op=dist.ReduceOp.SUM, group=self.group)
             if self.rank == 0:
@@ -127,3 +166,13 @@ class FramePipeline:
     def wait(self) -> None:
         self.compute.synchronize()
         self.comm.synchronize()
+
+
+def cpu_pipeline(stand_in, width: int, height: int, spp: int, tensors: dict, group=None, split: str = "samples") -> FramePipeline:
+    """A FramePipeline over CPU tensors for the gloo tests.  `stand_in` provides render_samples_device /
+    render_tiles_device / resolve_device with the renderer's signatures; they receive data_ptr() values, and
+    `tensors` (filled here) maps those back to the pipeline's buffers."""
+    pipe = FramePipeline(stand_in, width, height, spp, "cpu", group=group, split=split)
+    for t in pipe.accum + ([pipe.rgba8] if pipe.rgba8 is not None else []):
+        tensors[t.data_ptr()] = t
+    return pipe

@@ -160,6 +160,17 @@ class Renderer:
             self._check(n)
         return out[:n]
 
+    def integrate_times_ms(self, cap: int = 64) -> np.ndarray:
+        """Per launch: start of the launch to the end of its last integrate kernel (the dominant kernel alone)."""
+        out = np.zeros(cap, dtype=np.float32)
+        n = self._lib.rtr_integrate_times_ms(self._ctx, out.ctypes.data_as(C.POINTER(C.c_float)), cap)
+        if n < 0:
+            self._check(n)
+        return out[:n]
+
+    def kernel_name(self) -> str:
+        return (self._lib.rtr_kernel_name(self._ctx) or b"").decode()
+
     def selftest_sqrt(self) -> int:
         """Mismatches between the kernels' sqrt and sqrtf() over all 2^32 f32 bit patterns (must be 0)."""
         bad = C.c_uint64(0)

@@ -92,3 +92,85 @@ def test_sample_ranges_partition_the_samples():
             assert max(counts) - min(counts) <= 1
     with pytest.raises(ValueError):
         rd.sample_range(3, 3, 8)
+
+
+# ---- the DEFAULT decomposition: samples of every pixel split over the ranks (FramePipeline / bench.py) -------------
+class _StandInRenderer:
+    """The two entry points FramePipeline calls, computed on the CPU from per-sample radiance the ORACLE rendered:
+    render_samples_device STOREs the in-order partial sum of the rank's sample range for EVERY pixel, resolve_device is
+    render.rs:103-110.  (The product cannot compute without a GPU; only the sharding and the collective are under test.)"""
+
+    def __init__(self, per_sample, tensors):
+        self.per_sample = per_sample  # [spp, h, w, 3] float32: each sample's clamped radiance
+        self.tensors = tensors        # data_ptr -> tensor
+        self.calls = []
+
+    def render_samples_device(self, w, h, seed, begin, count, ptr, stream=0):
+        acc = np.zeros(self.per_sample.shape[1:], dtype=np.float32)
+        for s in range(begin, begin + count):  # in sample order, as the kernel adds them
+            acc = (acc + self.per_sample[s]).astype(np.float32)
+        t = self.tensors[ptr]
+        t[..., :3] = torch.from_numpy(acc)
+        t[..., 3] = 0.0
+        self.calls.append((begin, count))
+
+    def resolve_device(self, sum_ptr, spp, w, h, rgba_ptr, mean_ptr=0, stream=0):
+        acc = self.tensors[sum_ptr]
+        mean = acc[..., :3] / float(spp)
+        out = self.tensors[rgba_ptr]
+        out[..., :3] = torch.clamp(torch.sqrt(mean) * 255.0, 0, 255).to(torch.uint8)
+        out[..., 3] = 255
+
+
+def _sample_worker(rank, world, port, w, h, spp, samples_path, out_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    per_sample = np.load(samples_path)
+    tensors = {}
+    stand_in = _StandInRenderer(per_sample, tensors)
+    pipe = rd.cpu_pipeline(stand_in, w, h, spp, tensors, split="samples")
+    for frame in range(3):  # three frames through the two alternating sum buffers
+        pipe.submit(seed=frame)
+    pipe.wait()
+    assert stand_in.calls == [rd.sample_range(rank, world, spp)] * 3
+    if rank == 0:
+        np.savez(out_path, accum=pipe.accum[0].numpy(), rgba8=pipe.rgba8.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_gloo_sample_split_pipeline_sums_partial_sums(tmp_path, world):
+    """FramePipeline's default split over gloo: every rank integrates all pixels for its sample range, reduce(SUM) on rank
+    0 equals the sum of the ranks' partial sums exactly (same additions in rank order for 2 ranks; any order within 1e-6
+    relative in general) and the single-rank in-order sum within float-addition reordering; then resolve."""
+    w, h, spp = 33, 17, 13
+    scene = benchmark_scene(1)
+    per_sample = np.zeros((spp, h, w, 3), dtype=np.float32)
+    for s in range(spp):  # one-sample frames with different seeds stand in for the samples of one frame
+        _, mean, _ = pyoracle.OracleScene(scene).render(w, h, 100 + s, threads=0)
+        per_sample[s] = mean
+    samples_path, out_path = str(tmp_path / "samples.npy"), str(tmp_path / "out.npz")
+    np.save(samples_path, per_sample)
+    mp.spawn(_sample_worker, args=(world, _free_port(), w, h, spp, samples_path, out_path), nprocs=world, join=True)
+    out = np.load(out_path)
+    partial = []
+    for r in range(world):
+        b, c = rd.sample_range(r, world, spp)
+        acc = np.zeros((h, w, 3), dtype=np.float32)
+        for s in range(b, b + c):
+            acc = (acc + per_sample[s]).astype(np.float32)
+        partial.append(acc)
+    single = np.zeros((h, w, 3), dtype=np.float32)
+    for s in range(spp):
+        single = (single + per_sample[s]).astype(np.float32)
+    got = out["accum"][..., :3]
+    ref = np.sum(np.stack(partial).astype(np.float64), axis=0)
+    assert np.allclose(got, ref, rtol=1e-6, atol=0)  # the reduce is a sum of the partial sums
+    if world == 2:
+        assert np.array_equal(got, (partial[0] + partial[1]).astype(np.float32))
+    assert np.allclose(got, single, rtol=1e-5, atol=1e-7)  # only the order of the float additions differs from one rank
+    assert np.all(out["accum"][..., 3] == 0) and np.all(out["rgba8"][..., 3] == 255)
+    want8 = np.clip(np.sqrt(got / np.float32(spp)) * 255.0, 0, 255).astype(np.uint8)
+    assert np.max(np.abs(out["rgba8"][..., :3].astype(int) - want8.astype(int))) <= 1

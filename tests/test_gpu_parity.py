@@ -627,3 +627,86 @@ def test_sample_parallel_kernel_in_batches_and_sample_shards(gpu_renderer):
     for key, val in out.items():
         assert val[1] == base[1], key
         assert np.array_equal(val[0], base[0]) and np.array_equal(val[2], base[2]) and np.array_equal(val[3], base[3]), key
+
+
+# ---- robustness of the asynchronous entry points ----------------------------------------------------------------
+def _fresh_renderer(scene):
+    r = rt.Renderer(0)
+    r.upload_scene(scene)
+    return r
+
+
+def test_device_fault_word_fails_the_next_synchronising_call_once():
+    """The device's sticky fault word (set by a sample chunk that gave up waiting; here by option debug_fault) must turn
+    into RTR_ERR_HIP at every entry point that synchronises -- the device-resident render calls cannot report it -- and
+    be cleared by that report."""
+    import torch
+
+    from raytracingrust_amd._capi import RtrError
+
+    scene = benchmark_scene(4)
+    w, h = 64, 48
+    out = torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda:0")
+    for reader in ("stats", "kernel_times_ms", "segment_counts", "integrate_times_ms"):
+        r = _fresh_renderer(scene)
+        try:
+            r.set_option("debug_fault", "on")
+            r.render_frame_device(w, h, 1, out.data_ptr(), 0)  # asynchronous: returns RTR_OK
+            r.set_option("debug_fault", "off")
+            with pytest.raises(RtrError) as e:
+                getattr(r, reader)()
+            assert e.value.code == -3 and "fault" in str(e.value)
+            getattr(r, reader)()  # reported once, then clean
+            r.render_frame_device(w, h, 1, out.data_ptr(), 0)
+            assert r.stats().segments > 0
+        finally:
+            r.close()
+    r = _fresh_renderer(scene)
+    try:
+        r.set_option("debug_fault", "on")
+        with pytest.raises(RtrError):
+            r.render(w, h, seed=1)  # the host-output entry point synchronises itself
+    finally:
+        r.close()
+
+
+def test_sample_chunk_that_gives_up_is_reported():
+    """A frame of few tiles cut into chunks has successors resident next to their predecessors, so a chunk really
+    waits; with a zero timeout it gives up at once and the frame must be reported invalid.  With the default bound the
+    same launch is valid and bit-identical to the unchunked one."""
+    from raytracingrust_amd._capi import RtrError
+
+    scene = benchmark_scene(64)
+    r = _fresh_renderer(scene)
+    try:
+        r.set_option("sample_chunks", "1")
+        ref, _ = r.render(64, 64, seed=9)
+        r.set_option("sample_chunks", "4")
+        got, _ = r.render(64, 64, seed=9)
+        assert np.array_equal(ref, got)
+        r.set_option("chunk_timeout_ms", "0")
+        with pytest.raises(RtrError) as e:
+            for _ in range(8):  # (dispatch timing decides whether a particular launch has to wait at all)
+                r.render(64, 64, seed=9)
+        assert "timed out" in str(e.value)
+        r.set_option("chunk_timeout_ms", "10000")
+        got, _ = r.render(64, 64, seed=9)
+        assert np.array_equal(ref, got)
+    finally:
+        r.close()
+
+
+def test_frames_of_different_seeds_are_not_pixel_permutations(gpu_renderer):
+    """Both halves of the seed are hashed into both stream keys: with `pixel ^ seed_lo` alone the frame of seed s ^ d
+    was the frame of seed s with pixels p and p ^ d exchanged.  A scene of a uniform background only
+    isolates the camera jitter... every pixel is then equal; use the benchmark scene at 1 spp instead: the multiset of
+    pixel values must differ between seeds, and so must the frame under the XOR permutation."""
+    scene = benchmark_scene(1)
+    gpu_renderer.upload_scene(scene)
+    w, h = 64, 64
+    _, a = gpu_renderer.render(w, h, seed=0x1234, want_rgba8=False, want_mean=True)
+    for d in (1, 2, 64, 0x1235 ^ 0x1234):
+        _, b = gpu_renderer.render(w, h, seed=0x1234 ^ d, want_rgba8=False, want_mean=True)
+        idx = (np.arange(w * h) ^ d) % (w * h)
+        assert not np.array_equal(a.reshape(-1, 3)[idx], b.reshape(-1, 3))
+        assert not np.array_equal(np.sort(a.reshape(-1, 3), axis=0), np.sort(b.reshape(-1, 3), axis=0))

@@ -266,13 +266,17 @@ def test_options_are_validated_without_a_device():
         for name, good, bad in [("mesh_tree", ["reference", "sah"], "octree"), ("scene_tree", ["sah", "reference"], ""),
                                 ("leaf_pairs", ["off", "on"], "maybe"), ("tree_kernel", ["wave", "resumable", "samples", "auto"], "fast"),
                                 ("samples_batch", ["3", "0"], "-1"),
-                                ("sample_chunks", ["1", "7", "auto"], "0")]:
+                                ("sample_chunks", ["1", "7", "auto"], "0"),
+                                ("chunk_timeout_ms", ["0", "2.5", "10000"], "-1"), ("debug_fault", ["on", "off"], "1")]:
             for v in good:
                 r.set_option(name, v)
             with pytest.raises(rt.RtrError):
                 r.set_option(name, bad)
         with pytest.raises(rt.RtrError):
             r.set_option("no_such_option", "1")
+        # a host-only context has no device fault word to report: the synchronising readers stay RTR_OK / empty
+        assert r.stats().launches == 0 and len(r.kernel_times_ms()) == 0 and len(r.integrate_times_ms()) == 0
+        assert len(r.segment_counts()) == 0 and r.kernel_name() == ""
         s = simple_scene(1)
         r.upload_scene(s)
         base = r.scene_info()

@@ -271,7 +271,8 @@ def test_bvh_and_linear_world_agree():
 
 
 def test_rng_float_distributions():
-    """rand 0.8 float conversions: 23-bit grids; same k feeds all three forms."""
+    """rand 0.8 float conversions: 23-bit grids; the same k feeds both unit forms.  Kind 2 is
+    the rejection sampler's LCG sub-stream (one word of the path's stream seeds it): gen_range(-1.0..1.0)'s grid."""
     u = pyoracle.probe_rng(42, 7, 3, 0, 4096)
     h = pyoracle.probe_rng(42, 7, 3, 1, 4096)
     g = pyoracle.probe_rng(42, 7, 3, 2, 4096)
@@ -281,8 +282,11 @@ def test_rng_float_distributions():
     assert np.all(h * 2.0**23 == np.floor(h * 2.0**23))  # k * 2^-23
     assert np.all((g + 1.0) * 2.0**22 == np.floor((g + 1.0) * 2.0**22))
     assert np.array_equal(u, (h * f32(1.0 + 2.0**-23)).astype(np.float32))
-    assert np.array_equal(g, (h * f32(2.0) - f32(1.0)).astype(np.float32))
     assert abs(float(h.mean()) - 0.5) < 0.03 and abs(float(g.mean())) < 0.05
+    assert abs(float((g * g).mean()) - 1.0 / 3.0) < 0.03
+    # the ball sampler takes ONE word of the path's stream per call: the draw after a Lambertian bounce does not
+    # depend on how many candidates were rejected (probed through two streams that differ in the sample only)
+    assert not np.array_equal(pyoracle.probe_rng(42, 7, 4, 2, 16), g[:16])
     # streams are keyed by (seed, pixel, sample)
     assert not np.array_equal(pyoracle.probe_rng(42, 7, 4, 1, 16), h[:16])
     assert not np.array_equal(pyoracle.probe_rng(42, 8, 3, 1, 16), h[:16])
