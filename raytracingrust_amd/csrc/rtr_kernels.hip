@@ -338,7 +338,22 @@ RTR_DEV void gather_fence(const float4 &a, const float4 &b, const float4 &c, con
 struct Best {
     float t, u, v;
     uint32_t leaf; // REF_LEAF|type|L, or REF_NONE
+    float cull;    // boxes entered beyond this distance are skipped: t * kCullMargin (+inf until a leaf is hit)
 };
+// The reference visits every box the ray pierces (bvh.rs:160-166); the walk here skips a box whose entry distance lies
+// beyond the best hit so far.  Entry distances and hit distances are rounded results of different formulas, so a
+// primitive's computed t can undercut its own box's computed entry by a few ulps -- most visibly where a sphere touches
+// its box, or through the cancellation in a large sphere's root (r = 100: ~1e-5 absolute).  A box is therefore skipped
+// only when it is entered beyond the best hit by a relative margin of 2^-10, far above those errors and far below any
+// difference that would save work: with it every tree frame of the test-suite, at every size, is bit-identical to the
+// oracle's unculled recursive traversal (tests/test_gpu_parity.py); without it 0-20 pixels per 1080p frame differed in
+// the last bit.  Cost of the margin: below measurement noise.
+constexpr float kCullMargin = 1.0009765625f; // 1 + 2^-10
+RTR_DEV void best_reset(Best &b) { b.leaf = REF_NONE; b.t = __builtin_inff(); b.u = 0.0f; b.v = 0.0f; b.cull = __builtin_inff(); }
+RTR_DEV void best_take(Best &b, float t, float u, float v, uint32_t leaf) {
+    b.t = t; b.u = u; b.v = v; b.leaf = leaf;
+    b.cull = t * kCullMargin; // t > 0 (every accepted t exceeds tmin); a NaN t gives a NaN bound: nothing is culled
+}
 
 // Candidate acceptance inside one tree: the reference merges with `left < right ? left : right`
 // (bvh.rs:181-186): the smaller t wins and the later leaf in depth-first order wins exact ties.
@@ -358,115 +373,133 @@ RTR_DEV void test_leaf(const RenderParams &p, uint32_t ref, const Ray &r, float 
         // (Möller-Trumbore without its early exits -- all four tests on every lane -- was measured neutral.)
         if (triangle_t(mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y), mk(q1.z, q1.w, q2.x), r, t, u, v) &&
             accept_tree(best, t, ref)) {
-            best.t = t; best.u = u; best.v = v; best.leaf = ref;
+            best_take(best, t, u, v, ref);
         }
     } else if (VOL && (ref & REF_VOL)) {
         float t;
         // Volume::hit(ray, tmin, +inf) as called from the tree (bvh.rs:156)
         if (volume_t(mk(q0.x, q0.y, q0.z), q1.x, q1.y, r, a, __builtin_inff(), rng, t) && accept_tree(best, t, ref)) {
-            best.t = t; best.leaf = ref;
+            best_take(best, t, best.u, best.v, ref);
         }
     } else {
         float t;
         // Sphere::hit(ray, tmin, +inf) as called from the tree (bvh.rs:156)
         if (sphere_t(mk(q0.x, q0.y, q0.z), q1.x, r, a, __builtin_inff(), t) && accept_tree(best, t, ref)) {
-            best.t = t; best.leaf = ref;
+            best_take(best, t, best.u, best.v, ref);
         }
     }
 }
 
-// BvhNode::hit (bvh.rs:146-172) over the flattened tree rooted at `root`, whose own box has already been
-// tested by the caller.  The reference visits both children of every pierced box with the caller's
-// [tmin,tmax]; here children are visited nearest-entry first and a box is skipped when its entry lies
-// strictly beyond the best hit so far -- nothing inside it can win or tie.
-// tmax_box is the tmax the reference hands to AABB::hit: +inf from the scene tree, closest_so_far when a
-// mesh is reached from the linear world (scene.rs:147, mesh.rs:124-127).
+// One trip of BvhNode::hit (bvh.rs:146-172) over the flattened tree for a lane whose walk is in progress: a leaf test
+// (the second leaf of a collapsed pair follows in the next trip, no stack traffic) or a node step (both children's boxes
+// from one 64-byte record), then, when the lane has nowhere to descend, a pop.  The reference visits both children of
+// every pierced box with the caller's [tmin, tmax]; here children are visited nearest-entry first and a box is skipped
+// when it is entered beyond the best hit (Best::cull) -- nothing inside it can win or tie.
+// Volume leaves draw a random number on every visit (volume.rs:57), so a subtree that holds one is visited exactly when,
+// and in the order, the reference visits it: never culled by the best hit, left before right.
+// The body exists ONCE, as a macro: the wave-synchronous walk (`traverse`), the resumable walk (k_render_bvh), the
+// sample-parallel walk (k_render_bvh_sp) and the streaming walk (k_wf_intersect) expand it in place -- as a function
+// shared by several callers it compiled 6 ... 18 % slower in each of them.  Names it expects in scope: p, lane, cur, sp,
+// best, inv, a, rng, stk_ref, stk_t and the template flags VOL, MESH.
+//   RAY       the ray being walked
+//   TMAX_BOX  the tmax the reference hands to AABB::hit: +inf from the scene tree, closest_so_far when a mesh is reached
+//             from the linear world (scene.rs:147, mesh.rs:124-127)
+//   ON_EMPTY  statement executed when the stack runs empty: the walk is over
+// (Measured and not adopted: one kind of step -- node or leaf -- per trip, 0 ... -10 %; a while-while form, -20 %; both
+// triangles of a pair in one 96-byte gather, +13 VGPRs and no faster; an explicit bound test on the push, -1 ... -4 %:
+// one push per node record on the path, sp <= tree height < p.stack_cap by construction of the flattener, checked on the
+// host by tests/cpp/scene_sanity.cpp.)
+#define RTR_WALK_TRIP(RAY, TMAX_BOX, ON_EMPTY)                                                                           \
+    {                                                                                                                    \
+        RTR_LS1(1) RTR_LS(2, true)                                                                                       \
+        bool pop_ = false;                                                                                               \
+        /* (cur is never REF_NONE here: the callers test the root, a node step tests both children before descending) */ \
+        if (cur & REF_LEAF) {                                                                                            \
+            RTR_LS1(4) RTR_LS(3, true)                                                                                   \
+            /* a REF_PAIR ref stands for Split(leaf L, leaf L+1), its box already tested where the ref was read */       \
+            test_leaf<VOL>(p, cur & ~REF_PAIR, RAY, a, best, rng);                                                       \
+            pop_ = !(cur & REF_PAIR);                                                                                    \
+            cur = (cur & ~REF_PAIR) + 1u;                                                                                \
+        } else {                                                                                                         \
+            RTR_LS1(6) RTR_LS(5, true)                                                                                   \
+            const float4 *nq_ = reinterpret_cast<const float4 *>(p.nodes + cur);                                         \
+            float4 q0_ = nq_[0], q1_ = nq_[1], q2_ = nq_[2], q3_ = nq_[3];                                               \
+            gather_fence(q0_, q1_, q2_, q3_);                                                                            \
+            float lmin_[3] = {q0_.x, q0_.y, q0_.z}, lmax_[3] = {q0_.w, q1_.x, q1_.y};                                    \
+            float rmin_[3] = {q1_.z, q1_.w, q2_.x}, rmax_[3] = {q2_.y, q2_.z, q2_.w};                                    \
+            const uint32_t l_ = __float_as_uint(q3_.x), r_ = __float_as_uint(q3_.y);                                     \
+            const uint32_t flags_ = __float_as_uint(q3_.z);                                                              \
+            const bool lvol_ = VOL && (flags_ & NODE_LVOL), rvol_ = VOL && (flags_ & NODE_RVOL);                         \
+            bool hl_ = l_ != REF_NONE, hr_ = r_ != REF_NONE;                                                             \
+            float el_ = 0.0f, er_ = 0.0f;                                                                                \
+            if constexpr (MESH) {                                                                                        \
+                /* Mesh scenes: nearly every child is a Split node or a leaf pair, i.e. carries a box.  Both slab tests */ \
+                /* run unconditionally, side by side -- straight-line code instead of two exec-mask regions            */ \
+                /* (+2 ... +8 % on C3/C4; on sphere scenes, where half the children are bare leaves, it loses 4 %).    */ \
+                float tl_, tr_;                                                                                          \
+                const bool sl_ = slab(lmin_, lmax_, RAY, inv, TMAX_BOX, tl_);                                            \
+                const bool sr_ = slab(rmin_, rmax_, RAY, inv, TMAX_BOX, tr_);                                            \
+                const bool gl_ = (l_ & (REF_LEAF | REF_PAIR)) != REF_LEAF; /* Split nodes and leaf pairs carry a box */  \
+                const bool gr_ = (r_ & (REF_LEAF | REF_PAIR)) != REF_LEAF;                                               \
+                el_ = gl_ ? tl_ : 0.0f;                                                                                  \
+                er_ = gr_ ? tr_ : 0.0f;                                                                                  \
+                hl_ = hl_ && (!gl_ || (sl_ && (lvol_ || !(tl_ > best.cull)))); /* cull is +inf until a leaf is hit */    \
+                hr_ = hr_ && (!gr_ || (sr_ && (rvol_ || !(tr_ > best.cull))));                                           \
+            } else {                                                                                                     \
+                if (hl_ && (l_ & (REF_LEAF | REF_PAIR)) != REF_LEAF) {                                                   \
+                    hl_ = slab(lmin_, lmax_, RAY, inv, TMAX_BOX, el_);                                                   \
+                    if (!lvol_ && el_ > best.cull) hl_ = false;                                                          \
+                }                                                                                                        \
+                if (hr_ && (r_ & (REF_LEAF | REF_PAIR)) != REF_LEAF) {                                                   \
+                    hr_ = slab(rmin_, rmax_, RAY, inv, TMAX_BOX, er_);                                                   \
+                    if (!rvol_ && er_ > best.cull) hr_ = false;                                                          \
+                }                                                                                                        \
+            }                                                                                                            \
+            RTR_LS(14, hl_ && hr_)                                                                                       \
+            if (hl_ && hr_) {                                                                                            \
+                bool sw_ = er_ < el_;                                                                                    \
+                if (lvol_ && rvol_) sw_ = false; /* both subtrees draw: keep the reference's left-then-right order */    \
+                const uint32_t second_ = sw_ ? l_ : r_;                                                                  \
+                float esecond_ = sw_ ? el_ : er_;                                                                        \
+                if (sw_ ? lvol_ : rvol_) esecond_ = -__builtin_inff(); /* never culled at pop time */                    \
+                cur = sw_ ? r_ : l_;                                                                                     \
+                stk_ref[sp * 64 + lane] = second_;                                                                       \
+                stk_t[sp * 64 + lane] = esecond_;                                                                        \
+                sp++;                                                                                                    \
+            } else if (hl_) {                                                                                            \
+                cur = l_;                                                                                                \
+            } else if (hr_) {                                                                                            \
+                cur = r_;                                                                                                \
+            } else {                                                                                                     \
+                pop_ = true;                                                                                             \
+            }                                                                                                            \
+        }                                                                                                                \
+        if (pop_) {                                                                                                      \
+            RTR_LS1(8) RTR_LS(7, true)                                                                                   \
+            bool got_ = false;                                                                                           \
+            while (sp > 0) {                                                                                             \
+                RTR_LS1(9) RTR_LS(10, true)                                                                              \
+                sp--;                                                                                                    \
+                const uint32_t c_ = stk_ref[sp * 64 + lane];                                                             \
+                const float e_ = stk_t[sp * 64 + lane];                                                                  \
+                if (e_ > best.cull) continue; /* its box is entered beyond the best hit (never for -inf entries) */      \
+                cur = c_;                                                                                                \
+                got_ = true;                                                                                             \
+                break;                                                                                                   \
+            }                                                                                                            \
+            if (!got_) { ON_EMPTY; }                                                                                     \
+        }                                                                                                                \
+    }
+
+// BvhNode::hit over the tree rooted at `root`, whose own box has already been tested by the caller: the wave-synchronous
+// form (the wave returns when its slowest lane has finished).
 template <bool VOL, bool MESH>
 RTR_DEV void traverse(const RenderParams &p, uint32_t root, const Ray &r, V3 inv, float a, float tmax_box,
                       Best &best, uint32_t *stk_ref, float *stk_t, uint32_t lane, Rng &rng) {
-    // Volume leaves draw a random number on every visit (volume.rs:57), so a subtree that holds one is visited
-    // exactly when, and in the order, the reference visits it: never culled by the best hit, left before right.
     uint32_t sp = 0;
     uint32_t cur = root;
-    for (;;) {
-        bool pop = false;
-        // (cur is never REF_NONE here: the callers test the root, a node step tests both children before descending)
-        if (cur & REF_LEAF) {
-            // a REF_PAIR ref stands for Split(leaf L, leaf L+1), its box already tested where the ref was read
-            // (Both triangles of a pair in one 96-byte gather was measured no faster: +13 VGPRs.)
-            test_leaf<VOL>(p, cur & ~REF_PAIR, r, a, best, rng);
-            pop = !(cur & REF_PAIR);
-            cur = (cur & ~REF_PAIR) + 1u; // the pair's second leaf: the next trip, no stack traffic
-        } else {
-            const float4 *nq = reinterpret_cast<const float4 *>(p.nodes + cur);
-            float4 q0 = nq[0], q1 = nq[1], q2 = nq[2], q3 = nq[3];
-#ifndef RTR_X_NO_GATHER_FENCE
-            gather_fence(q0, q1, q2, q3);
-#endif
-            float lmin[3] = {q0.x, q0.y, q0.z}, lmax[3] = {q0.w, q1.x, q1.y};
-            float rmin[3] = {q1.z, q1.w, q2.x}, rmax[3] = {q2.y, q2.z, q2.w};
-            uint32_t l = __float_as_uint(q3.x), rr = __float_as_uint(q3.y);
-            const uint32_t flags = __float_as_uint(q3.z);
-            const bool lvol = VOL && (flags & NODE_LVOL), rvol = VOL && (flags & NODE_RVOL);
-            bool hl = l != REF_NONE, hr = rr != REF_NONE;
-            float el = 0.0f, er = 0.0f;
-            if constexpr (MESH) {
-                // Mesh scenes: nearly every child is a Split node or a leaf pair, i.e. carries a box.  Both slab tests
-                // run unconditionally, side by side -- straight-line code instead of two exec-mask regions
-                // (+2 ... +8 % on C3/C4; on sphere scenes, where half the children are bare leaves, it loses 4 %).
-                float tl, tr;
-                const bool sl = slab(lmin, lmax, r, inv, tmax_box, tl);
-                const bool sr = slab(rmin, rmax, r, inv, tmax_box, tr);
-                const bool gl = (l & (REF_LEAF | REF_PAIR)) != REF_LEAF; // Split nodes and collapsed leaf pairs carry a box
-                const bool gr = (rr & (REF_LEAF | REF_PAIR)) != REF_LEAF;
-                el = gl ? tl : 0.0f;
-                er = gr ? tr : 0.0f;
-                hl = hl && (!gl || (sl && (lvol || !(tl > best.t)))); // best.t is +inf until a leaf is hit
-                hr = hr && (!gr || (sr && (rvol || !(tr > best.t))));
-            } else {
-                if (hl && (l & (REF_LEAF | REF_PAIR)) != REF_LEAF) {
-                    hl = slab(lmin, lmax, r, inv, tmax_box, el);
-                    if (!lvol && el > best.t) hl = false;
-                }
-                if (hr && (rr & (REF_LEAF | REF_PAIR)) != REF_LEAF) {
-                    hr = slab(rmin, rmax, r, inv, tmax_box, er);
-                    if (!rvol && er > best.t) hr = false;
-                }
-            }
-            if (hl && hr) {
-                bool sw = er < el;
-                if (lvol && rvol) sw = false; // both subtrees draw: keep the reference's left-then-right order
-                uint32_t second = sw ? l : rr;
-                float esecond = sw ? el : er;
-                if (sw ? lvol : rvol) esecond = -__builtin_inff(); // never culled at pop time
-                cur = sw ? rr : l;
-                // One push per Split node on the path: sp <= tree height < p.stack_cap, by construction of the flattener
-                // (checked on the host by tests/cpp/scene_sanity.cpp); an explicit bound test here cost 1-4 %.
-                stk_ref[sp * 64 + lane] = second;
-                stk_t[sp * 64 + lane] = esecond;
-                sp++;
-            } else if (hl) {
-                cur = l;
-            } else if (hr) {
-                cur = rr;
-            } else {
-                pop = true;
-            }
-        }
-        if (pop) {
-            bool got = false;
-            while (sp > 0) {
-                sp--;
-                uint32_t c = stk_ref[sp * 64 + lane];
-                float e = stk_t[sp * 64 + lane];
-                if (e > best.t) continue; // its box is entered beyond the best hit (never for -inf entries)
-                cur = c;
-                got = true;
-                break;
-            }
-            if (!got) break;
-        }
-    }
+    bool walking = true;
+    while (walking) RTR_WALK_TRIP(r, tmax_box, walking = false)
 }
 
 struct Hit {
@@ -647,7 +680,7 @@ RTR_DEV bool world_hit(const RenderParams &p, const Ray &r, Hit &h, uint32_t *st
     } else {
         const V3 inv = mk(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z); // aabb.rs:86,103,120, hoisted per ray
         Best best;
-        best.leaf = REF_NONE; best.t = __builtin_inff(); best.u = 0.0f; best.v = 0.0f;
+        best_reset(best);
         if constexpr (WORLD == WORLD_BVH) {
             uint32_t root = p.root_ref;
             bool go = root != REF_NONE;
@@ -672,11 +705,11 @@ RTR_DEV bool world_hit(const RenderParams &p, const Ray &r, Hit &h, uint32_t *st
                     const bool got = (VOL && (ref & REF_VOL)) ? volume_t(mk(q0.x, q0.y, q0.z), q1.x, q1.y, r, a, closest, rng, t)
                                                      : sphere_t(mk(q0.x, q0.y, q0.z), q1.x, r, a, closest, t);
                     if (got) {
-                        closest = t; best.t = t; best.leaf = ref;
+                        closest = t; best_take(best, t, 0.0f, 0.0f, ref);
                     }
                 } else {
                     Best local;
-                    local.leaf = REF_NONE; local.t = __builtin_inff(); local.u = 0.0f; local.v = 0.0f;
+                    best_reset(local);
                     bool go = true;
                     if ((ref & (REF_LEAF | REF_PAIR)) != REF_LEAF) {
                         float e;
@@ -1205,7 +1238,7 @@ __global__ __launch_bounds__(64, RTR_X_BVH_WAVES) void k_render_bvh(const Render
     // the walk's per-lane state (world_hit + traverse of k_render, unrolled into the loop below)
     uint32_t cur = REF_NONE, sp = 0;
     Best best;
-    best.leaf = REF_NONE; best.t = __builtin_inff(); best.u = 0.0f; best.v = 0.0f;
+    best_reset(best);
     V3 inv = mk(0.0f, 0.0f, 0.0f);
     float a = 0.0f;
     bool walking = false;
@@ -1213,7 +1246,7 @@ __global__ __launch_bounds__(64, RTR_X_BVH_WAVES) void k_render_bvh(const Render
         nseg++;
         a = dot(ray.d, ray.d);
         inv = mk(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z);
-        best.leaf = REF_NONE; best.t = __builtin_inff(); best.u = 0.0f; best.v = 0.0f;
+        best_reset(best);
         const uint32_t root = p.root_ref;
         bool go = root != REF_NONE;
         if (go && (root & (REF_LEAF | REF_PAIR)) != REF_LEAF) {
@@ -1231,83 +1264,14 @@ __global__ __launch_bounds__(64, RTR_X_BVH_WAVES) void k_render_bvh(const Render
         if (alive_mask == 0ull) break;
         const uint32_t quorum = (uint32_t)__popcll(alive_mask) * RTR_TREE_QUORUM_NUM / RTR_TREE_QUORUM_DEN;
         // ---- walk: one trip per iteration for every lane still walking ----
-        // (The trip is `traverse`'s loop body, repeated here on purpose: as one function shared by both callers it
-        // compiled 6 ... 18 % slower in either.)
+        // (RTR_WALK_TRIP: the one trip body every walk expands in place.)
         while ((uint32_t)__popcll(__ballot(walking)) > quorum) {
             // (Taking only the kind of step -- node or leaf -- that more walkers wait for was measured 0 ... -10 %:
             // with both bodies in one trip their gathers overlap.)
             // kWalkUnroll trips per quorum check: C3 +15 %, C4 +5 % over one (2, 3, 4, 6, 8 measured: flat from 3 on)
 #pragma unroll
             for (uint32_t rep = 0; rep < kWalkUnroll; rep++)
-            if (walking) {
-                bool pop = false;
-                if (cur & REF_LEAF) {
-                    test_leaf<VOL>(p, cur & ~REF_PAIR, ray, a, best, rng);
-                    pop = !(cur & REF_PAIR);
-                    cur = (cur & ~REF_PAIR) + 1u;
-                } else {
-                    const float4 *nq = reinterpret_cast<const float4 *>(p.nodes + cur);
-                    float4 q0 = nq[0], q1 = nq[1], q2 = nq[2], q3 = nq[3];
-                    gather_fence(q0, q1, q2, q3);
-                    float lmin[3] = {q0.x, q0.y, q0.z}, lmax[3] = {q0.w, q1.x, q1.y};
-                    float rmin[3] = {q1.z, q1.w, q2.x}, rmax[3] = {q2.y, q2.z, q2.w};
-                    uint32_t l = __float_as_uint(q3.x), rr = __float_as_uint(q3.y);
-                    const uint32_t flags = __float_as_uint(q3.z);
-                    const bool lvol = VOL && (flags & NODE_LVOL), rvol = VOL && (flags & NODE_RVOL);
-                    bool hl = l != REF_NONE, hr = rr != REF_NONE;
-                    float el = 0.0f, er = 0.0f;
-                    if constexpr (MESH) {
-                        float tl, tr;
-                        const bool sl = slab(lmin, lmax, ray, inv, __builtin_inff(), tl);
-                        const bool sr = slab(rmin, rmax, ray, inv, __builtin_inff(), tr);
-                        const bool gl = (l & (REF_LEAF | REF_PAIR)) != REF_LEAF;
-                        const bool gr = (rr & (REF_LEAF | REF_PAIR)) != REF_LEAF;
-                        el = gl ? tl : 0.0f;
-                        er = gr ? tr : 0.0f;
-                        hl = hl && (!gl || (sl && (lvol || !(tl > best.t))));
-                        hr = hr && (!gr || (sr && (rvol || !(tr > best.t))));
-                    } else {
-                        if (hl && (l & (REF_LEAF | REF_PAIR)) != REF_LEAF) {
-                            hl = slab(lmin, lmax, ray, inv, __builtin_inff(), el);
-                            if (!lvol && el > best.t) hl = false;
-                        }
-                        if (hr && (rr & (REF_LEAF | REF_PAIR)) != REF_LEAF) {
-                            hr = slab(rmin, rmax, ray, inv, __builtin_inff(), er);
-                            if (!rvol && er > best.t) hr = false;
-                        }
-                    }
-                    if (hl && hr) {
-                        bool sw = er < el;
-                        if (lvol && rvol) sw = false;
-                        uint32_t second = sw ? l : rr;
-                        float esecond = sw ? el : er;
-                        if (sw ? lvol : rvol) esecond = -__builtin_inff();
-                        cur = sw ? rr : l;
-                        stk_ref[sp * 64 + lane] = second;
-                        stk_t[sp * 64 + lane] = esecond;
-                        sp++;
-                    } else if (hl) {
-                        cur = l;
-                    } else if (hr) {
-                        cur = rr;
-                    } else {
-                        pop = true;
-                    }
-                }
-                if (pop) {
-                    bool got = false;
-                    while (sp > 0) {
-                        sp--;
-                        uint32_t c = stk_ref[sp * 64 + lane];
-                        float e = stk_t[sp * 64 + lane];
-                        if (e > best.t) continue;
-                        cur = c;
-                        got = true;
-                        break;
-                    }
-                    if (!got) walking = false;
-                }
-            }
+            if (walking) RTR_WALK_TRIP(ray, __builtin_inff(), walking = false)
         }
         // ---- the lanes whose walk has ended: the rest of trace_ray, then the next segment or the next sample ----
         if (alive && !walking) {
@@ -1418,7 +1382,7 @@ __global__ __launch_bounds__(64, 6) void k_render_bvh_sp(const RenderParams p) {
     // the walk's per-lane state (world_hit + traverse of k_render, unrolled into the loop below)
     uint32_t cur = REF_NONE, sp = 0;
     Best best;
-    best.leaf = REF_NONE; best.t = __builtin_inff(); best.u = 0.0f; best.v = 0.0f;
+    best_reset(best);
     V3 inv = mk(0.0f, 0.0f, 0.0f);
     float a = 0.0f;
     bool walking = false;
@@ -1426,7 +1390,7 @@ __global__ __launch_bounds__(64, 6) void k_render_bvh_sp(const RenderParams p) {
         nseg++;
         a = dot(ray.d, ray.d);
         inv = mk(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z);
-        best.leaf = REF_NONE; best.t = __builtin_inff(); best.u = 0.0f; best.v = 0.0f;
+        best_reset(best);
         const uint32_t root = p.root_ref;
         bool go = root != REF_NONE;
         if (go && (root & (REF_LEAF | REF_PAIR)) != REF_LEAF) {
@@ -1474,89 +1438,14 @@ __global__ __launch_bounds__(64, 6) void k_render_bvh_sp(const RenderParams p) {
         const uint32_t quorum = (uint32_t)__popcll(alive_mask) * RTR_TREE_QUORUM_NUM / RTR_TREE_QUORUM_DEN;
         RTR_LS1(0) RTR_LS(15, alive)
         // ---- walk: one trip per iteration for every lane still walking ----
-        // (The trip is `traverse`'s loop body, repeated here on purpose: as one function shared by both callers it
-        // compiled 6 ... 18 % slower in either.)
+        // (RTR_WALK_TRIP: the one trip body every walk expands in place.)
         while ((uint32_t)__popcll(__ballot(walking)) > quorum) {
             // (Taking only the kind of step -- node or leaf -- that more walkers wait for was measured 0 ... -10 %:
             // with both bodies in one trip their gathers overlap.)
             // kWalkUnroll trips per quorum check: C3 +15 %, C4 +5 % over one (2, 3, 4, 6, 8 measured: flat from 3 on)
 #pragma unroll
             for (uint32_t rep = 0; rep < kWalkUnroll; rep++)
-            if (walking) {
-                RTR_LS1(1) RTR_LS(2, true)
-                bool pop = false;
-                if (cur & REF_LEAF) {
-                    RTR_LS1(4) RTR_LS(3, true)
-                    test_leaf<VOL>(p, cur & ~REF_PAIR, ray, a, best, rng);
-                    pop = !(cur & REF_PAIR);
-                    cur = (cur & ~REF_PAIR) + 1u;
-                } else {
-                    RTR_LS1(6) RTR_LS(5, true)
-                    const float4 *nq = reinterpret_cast<const float4 *>(p.nodes + cur);
-                    float4 q0 = nq[0], q1 = nq[1], q2 = nq[2], q3 = nq[3];
-                    gather_fence(q0, q1, q2, q3);
-                    float lmin[3] = {q0.x, q0.y, q0.z}, lmax[3] = {q0.w, q1.x, q1.y};
-                    float rmin[3] = {q1.z, q1.w, q2.x}, rmax[3] = {q2.y, q2.z, q2.w};
-                    uint32_t l = __float_as_uint(q3.x), rr = __float_as_uint(q3.y);
-                    const uint32_t flags = __float_as_uint(q3.z);
-                    const bool lvol = VOL && (flags & NODE_LVOL), rvol = VOL && (flags & NODE_RVOL);
-                    bool hl = l != REF_NONE, hr = rr != REF_NONE;
-                    float el = 0.0f, er = 0.0f;
-                    if constexpr (MESH) {
-                        float tl, tr;
-                        const bool sl = slab(lmin, lmax, ray, inv, __builtin_inff(), tl);
-                        const bool sr = slab(rmin, rmax, ray, inv, __builtin_inff(), tr);
-                        const bool gl = (l & (REF_LEAF | REF_PAIR)) != REF_LEAF;
-                        const bool gr = (rr & (REF_LEAF | REF_PAIR)) != REF_LEAF;
-                        el = gl ? tl : 0.0f;
-                        er = gr ? tr : 0.0f;
-                        hl = hl && (!gl || (sl && (lvol || !(tl > best.t))));
-                        hr = hr && (!gr || (sr && (rvol || !(tr > best.t))));
-                    } else {
-                        if (hl && (l & (REF_LEAF | REF_PAIR)) != REF_LEAF) {
-                            hl = slab(lmin, lmax, ray, inv, __builtin_inff(), el);
-                            if (!lvol && el > best.t) hl = false;
-                        }
-                        if (hr && (rr & (REF_LEAF | REF_PAIR)) != REF_LEAF) {
-                            hr = slab(rmin, rmax, ray, inv, __builtin_inff(), er);
-                            if (!rvol && er > best.t) hr = false;
-                        }
-                    }
-                    RTR_LS(14, hl && hr)
-                    if (hl && hr) {
-                        bool sw = er < el;
-                        if (lvol && rvol) sw = false;
-                        uint32_t second = sw ? l : rr;
-                        float esecond = sw ? el : er;
-                        if (sw ? lvol : rvol) esecond = -__builtin_inff();
-                        cur = sw ? rr : l;
-                        stk_ref[sp * 64 + lane] = second;
-                        stk_t[sp * 64 + lane] = esecond;
-                        sp++;
-                    } else if (hl) {
-                        cur = l;
-                    } else if (hr) {
-                        cur = rr;
-                    } else {
-                        pop = true;
-                    }
-                }
-                if (pop) {
-                    RTR_LS1(8) RTR_LS(7, true)
-                    bool got = false;
-                    while (sp > 0) {
-                        RTR_LS1(9) RTR_LS(10, true)
-                        sp--;
-                        uint32_t c = stk_ref[sp * 64 + lane];
-                        float e = stk_t[sp * 64 + lane];
-                        if (e > best.t) continue;
-                        cur = c;
-                        got = true;
-                        break;
-                    }
-                    if (!got) walking = false;
-                }
-            }
+            if (walking) RTR_WALK_TRIP(ray, __builtin_inff(), walking = false)
         }
         // ---- the lanes whose walk has ended: the rest of trace_ray, then the next segment or the next sample ----
         if (alive && !walking) {

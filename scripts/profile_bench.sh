@@ -1,8 +1,11 @@
 #!/bin/bash
-# Profiles the headline bench on the GPU box: kernel trace + stats, then PMC passes (each in its own run,
-# never combined with trace domains).  Usage (through gpurun): bash scripts/profile_bench.sh <tag> [bench args]
+# Profiles one bench.py workload on the GPU box: kernel trace + stats, then PMC passes (each in its own run, never
+# combined with trace domains).  Writes gpurun_out/prof_<tag>/{summary_tables.txt,<workload>.json}; the JSON carries the
+# hash of the kernel sources it was taken on (raytracingrust_amd.build.kernel_sha) and is what bench.py reads from
+# profiles/<round>/ -- copy both files there and commit them.
+# Usage (through gpurun): bash scripts/profile_bench.sh <tag> [bench args]
 set -u
-TAG=${1:-r01}; shift || true
+TAG=${1:-r02}; shift || true
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
@@ -20,8 +23,8 @@ echo "pmc_fetch rc=$?" >> "$OUT/summary.txt"
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- python3 "$ROOT/bench.py" $ARGS > "$OUT/pmc_write.log" 2>&1
 echo "pmc_write rc=$?" >> "$OUT/summary.txt"
 cd "$ROOT"
-python3 scripts/summarize_prof.py "$OUT" > "$OUT/summary_tables.txt" 2>&1
-cat "$OUT/summary.txt"; tail -40 "$OUT/summary_tables.txt"
+python3 scripts/summarize_prof.py "$OUT" $ARGS > "$OUT/summary_tables.txt" 2>&1
+cat "$OUT/summary.txt"; tail -45 "$OUT/summary_tables.txt"
 # drop bulky raw files, keep csv
 find "$OUT" -name "*.db" -delete
 du -sh "$OUT"

@@ -43,5 +43,4 @@ def test_hip_reproduces_golden(gpu_renderer, name):
     c = compare(mean, rgba, g["mean"], g["rgba"])
     assert st.segments == int(g["segments"]), name
     assert max(c["rel_l2"]) <= 1e-4 and c["max_u8_delta"] <= 1, (name, c)
-    has_mesh = any(isinstance(o, rt.Mesh) for o in scene.objects)
-    assert c["mismatched_pixels"] <= (2 if has_mesh else 0), (name, c)
+    assert c["mismatched_pixels"] == 0, (name, c)
