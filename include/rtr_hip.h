@@ -201,18 +201,26 @@ int rtr_abi_version(void);
  *                 ranks is stored inside its parent (same box test, same two leaf tests in the same order, one traversal
  *                 step fewer).  Decisions are identical either way -- frames are bit-identical; "off" exists for A/B
  *                 measurements.
- *   "tree_kernel" = "auto" (default) | "samples" | "resumable" | "wave" (applied at the next render): which kernel
+ *   "tree_kernel" = "auto" (default) | "stream" | "samples" | "resumable" | "wave" (applied at the next render): which kernel
  *                 walks the tree when enable_bvh_tree is set.  "wave": a wave returns from world.hit when its slowest
  *                 lane has finished.  "resumable": the walk is a per-lane state machine inside the main loop, so lanes
  *                 that are done shade and start their next ray while the others keep walking.  "samples": the same
  *                 walk, but a lane takes (sample, pixel) pairs of its tile instead of owning one pixel; each sample's
  *                 clamped radiance is written to device memory (16 bytes per sample, in batches of at most 16 GiB)
- *                 and a second kernel adds every pixel's samples in index order.  Every lane-level operation and
- *                 every addition is the same in all three: bit-identical frames.  "auto": trees of 32 leaves or more
+ *                 and a second kernel adds every pixel's samples in index order.  "stream": the streaming wavefront --
+ *                 the paths of a batch of samples live in device memory (65 + 4 * max_ray_depth bytes each) and every
+ *                 stage is its own kernel: generate, then per recursion depth an intersect kernel whose lanes take the
+ *                 next waiting path the moment their walk ends and a shade kernel over full waves, then the same
+ *                 in-order sum as "samples".  Every lane-level operation and every addition is the same in all of
+ *                 them: bit-identical frames.  "auto": trees of 32 leaves or more
  *                 take "samples" (inside tile-sharded launches, where it does not apply: "resumable" for scenes with
  *                 meshes, else "wave"); smaller trees "wave". */
-/*   "samples_batch" = "0" (default: as many samples as 16 GiB hold) | N: samples per batch of the "samples" kernel's
- *                 radiance buffer; a pixel's running sum is carried from batch to batch, so any N gives the same frame. */
+/*   "samples_batch" = "0" (default: what half of the free device memory holds, at most 16 GiB of radiance and 64
+ *                 samples for "stream") | N: samples per batch of the "samples" / "stream" kernels' buffers; a pixel's
+ *                 running sum is carried from batch to batch, so any N gives the same frame.  A batch whose allocation
+ *                 fails is halved and retried.
+ *   "stream_flush" = "8" (default) | 1 .. 64: finished walks a wave of the "stream" intersect kernel collects before it
+ *                 stores their hits and hands the lanes new paths (tuning; any value gives the same frame). */
 /*   "sample_chunks" = "auto" (default) | "1" .. "4096" (applied at the next render): pieces every pixel's sample range
  *                 is cut into inside one launch.  Each piece continues the running sums of the one before it in the
  *                 same order, so the frame is bit-identical for every value; more pieces shorten the tail of a launch

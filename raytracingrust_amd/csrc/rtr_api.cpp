@@ -30,6 +30,12 @@ hipError_t launch_sum_samples(const float *samples, uint32_t n_samples, float *a
                               uint32_t n_pixels, float *sum_rgba, uint8_t *rgba8, float *mean_rgb, hipStream_t stream);
 hipError_t launch_selftest_sqrt(unsigned long long *d_mismatches, hipStream_t stream);
 hipError_t launch_debug_fault(unsigned long long *fault, hipStream_t stream);
+hipError_t launch_wf_generate(const RenderParams &p, uint32_t batch_samples, hipStream_t stream);
+hipError_t launch_wf_intersect(const RenderParams &p, uint32_t grid, hipStream_t stream);
+hipError_t launch_wf_shade(const RenderParams &p, uint32_t grid, hipStream_t stream);
+uint32_t wf_resident_waves(const RenderParams &p, bool shade);
+uint32_t wf_intersect_lds_bytes(const RenderParams &p);
+hipError_t wf_intersect_attributes(const RenderParams &p, int *vgprs);
 hipError_t launch_selftest_div(float d, uint32_t lo_bits, uint32_t hi_bits, unsigned long long *d_mismatches, hipStream_t stream);
 } // namespace rtr
 
@@ -50,7 +56,10 @@ struct rtr_context {
     hipStream_t stream = nullptr;
     std::string error;
     rtr::BuildOptions build_options;
-    int tree_kernel = 0; // option "tree_kernel": 0 auto, 1 resumable, 2 wave
+    int tree_kernel = 0; // option "tree_kernel": 0 auto, 1 resumable, 2 wave, 3 samples, 4 stream
+    uint32_t wf_flush = 8; // option "stream_flush": finished walks a wave of k_wf_intersect collects before storing them
+    void *d_wf = nullptr;  // streaming wavefront: the path records of one batch (ray, hit, state, chain, stage)
+    size_t wf_cap = 0;
     int sample_chunks = 0; // option "sample_chunks": 0 auto, else the number of pieces
     double chunk_timeout_s = 10.0; // option "chunk_timeout_ms": bound of a sample chunk's wait for its predecessor
     bool debug_fault = false;      // option "debug_fault": the next launches set bit 1 of the fault word
@@ -209,9 +218,12 @@ int launch_frame(rtr_context *ctx, const rtr_camera *camera, const rtr_settings 
     // Measured at 1080p/64 spp against the resumable walk: C3 +19 %, C4 +16 %, C1 +10 %.
     // Tiny trees keep the wave kernel under "auto": the per-sample set-up and the trip through memory do not pay for
     // their cheap samples (5-sphere tree -13 %; 102 spheres +8 % at 1080p, +1 % at 4K; meshes +20 %).
-    p.sample_parallel = ((ctx->tree_kernel == 3 || (ctx->tree_kernel == 0 && fs.leaf_hot.size() >= 32u)) && st->enable_bvh_tree &&
-                         p.max_depth > 0u && sample_count > 0u && n_shards == 1u) ? 1u : 0u;
-    if (ctx->tree_kernel == 3 && !p.sample_parallel) p.resumable_walk = 1u;
+    const bool per_sample_ok = st->enable_bvh_tree && p.max_depth > 0u && sample_count > 0u && n_shards == 1u;
+    // "stream": path state in HBM, one kernel per stage and depth (rtr_kernels.hip "streaming wavefront"); same conditions
+    const bool streaming = ctx->tree_kernel == 4 && per_sample_ok;
+    p.sample_parallel = ((ctx->tree_kernel == 3 || (ctx->tree_kernel == 0 && fs.leaf_hot.size() >= 32u)) && per_sample_ok) ? 1u : 0u;
+    if ((ctx->tree_kernel == 3 || ctx->tree_kernel == 4) && !p.sample_parallel && !streaming) p.resumable_walk = 1u;
+    if (streaming) p.sample_parallel = 1u; // shares the per-sample radiance buffer and k_sum_samples with "samples"
     p.root_ref = fs.root_ref;
     std::memcpy(p.root_box, fs.root_box, sizeof p.root_box);
     p.nodes = static_cast<const rtr::DevNode *>(ctx->d_nodes);
@@ -288,17 +300,44 @@ int launch_frame(rtr_context *ctx, const rtr_camera *camera, const rtr_settings 
         p.chunks = want;
         p.chunk_taper = p.world == rtr::WORLD_LINEAR_SPHERES ? 6u : 0u; // see chunk_boundary
     }
-    // k_render_bvh_sp's sample buffer: sample_count * W * H float4, in batches of at most 16 GiB (1080p: 512 samples)
+    // Per-sample radiance buffer of the "samples" and "stream" tree kernels: sample_count * W * H float4, filled in
+    // batches ("stream" adds its path records: 65 + 4 * max_ray_depth bytes per path of the batch).  A batch takes at
+    // most half of the device memory that is free right now and at most 16 GiB of radiance; any batch size gives the
+    // same frame (the running sums are carried from batch to batch), so an allocation that fails is retried with half
+    // the batch before the call gives up.
     uint32_t batch_samples = sample_count;
+    uint64_t wf_paths_per_sample = 0, wf_bytes_per_path = 0;
     if (p.sample_parallel) {
         const uint64_t per_sample = (uint64_t)width * height * 4ull * sizeof(float);
-        batch_samples = (uint32_t)std::max<uint64_t>(1ull, std::min<uint64_t>(sample_count, (16ull << 30) / per_sample));
+        uint64_t per_sample_total = per_sample;
+        if (streaming) {
+            wf_paths_per_sample = (uint64_t)p.tiles_total * 64ull;
+            wf_bytes_per_path = 32ull + 16ull + 16ull + 4ull * p.max_depth + 1ull;
+            per_sample_total += wf_paths_per_sample * wf_bytes_per_path;
+        }
+        size_t free_b = 0, total_b = 0;
+        uint64_t budget = 16ull << 30;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+            const uint64_t held = (uint64_t)ctx->samples_cap + (uint64_t)ctx->wf_cap; // ours already: reusable
+            budget = std::max<uint64_t>(per_sample_total, ((uint64_t)free_b + held) / 2ull);
+        }
+        uint64_t fit = std::max<uint64_t>(1ull, std::min<uint64_t>(budget / per_sample_total, (16ull << 30) / per_sample));
+        if (streaming) fit = std::min<uint64_t>(fit, std::min<uint64_t>(0x7FFFFFFFull / wf_paths_per_sample, 65535ull));
+        if (streaming && fit > 64ull) fit = 64ull; // more samples per batch buy nothing: a batch is ~15 launches
+        batch_samples = (uint32_t)std::max<uint64_t>(1ull, std::min<uint64_t>(sample_count, fit));
         if (ctx->samples_batch > 0u) batch_samples = std::min(batch_samples, ctx->samples_batch);
-        int rc = ensure_scratch(ctx, &ctx->d_samples, &ctx->samples_cap, (size_t)(per_sample * batch_samples));
-        if (rc) return rc;
+        for (;;) {
+            int rc = ensure_scratch(ctx, &ctx->d_samples, &ctx->samples_cap, (size_t)(per_sample * batch_samples));
+            if (!rc && streaming) rc = ensure_scratch(ctx, &ctx->d_wf, &ctx->wf_cap, (size_t)(wf_paths_per_sample * batch_samples * wf_bytes_per_path + 256ull));
+            if (!rc) break;
+            if (batch_samples == 1u) return rc;
+            (void)hipGetLastError(); // out of memory: the same frame in smaller batches
+            batch_samples = std::max(1u, batch_samples / 2u);
+        }
         p.samples = static_cast<float *>(ctx->d_samples);
         if (batch_samples < sample_count) { // running sums between batches
-            if ((rc = ensure_scratch(ctx, &ctx->d_carry, &ctx->carry_cap, (size_t)per_sample))) return rc;
+            int rc = ensure_scratch(ctx, &ctx->d_carry, &ctx->carry_cap, (size_t)per_sample);
+            if (rc) return rc;
         }
     }
     if (p.chunks > 1u && !p.sample_parallel) {
@@ -317,13 +356,40 @@ int launch_frame(rtr_context *ctx, const rtr_camera *camera, const rtr_settings 
     if (grid > 0 && p.sample_parallel) {
         // batch by batch: render the batch's samples, then add them to each pixel's sum in index order; the last
         // batch's k_sum_samples finishes the pixel (or stores the launch's partial sum)
+        uint32_t wf_grid_i = 0, wf_grid_s = 0;
+        if (streaming) {
+            p.wf_flush = ctx->wf_flush;
+            wf_grid_i = std::max(1u, rtr::wf_resident_waves(p, false));
+            wf_grid_s = std::max(1u, rtr::wf_resident_waves(p, true));
+            ctx->last_lds = rtr::wf_intersect_lds_bytes(p);
+        }
         for (uint32_t done = 0; done < sample_count; done += batch_samples) {
             rtr::RenderParams b = p;
             b.sample_begin = sample_begin + done;
             b.sample_count = std::min(batch_samples, sample_count - done);
             b.chunks = std::max(1u, std::min(p.chunks, b.sample_count));
             const bool first = done == 0u, last = done + b.sample_count == sample_count;
-            RTR_HIP_TRY(ctx, rtr::launch_render(b, grid * b.chunks, lds_bytes, stream));
+            if (!streaming) {
+                RTR_HIP_TRY(ctx, rtr::launch_render(b, grid * b.chunks, lds_bytes, stream));
+            } else {
+                // the batch's path records, carved out of one allocation (16-byte aligned pieces first)
+                const uint64_t n = wf_paths_per_sample * b.sample_count;
+                uint8_t *base = static_cast<uint8_t *>(ctx->d_wf);
+                b.wf_ray = reinterpret_cast<float *>(base); base += n * 32ull;
+                b.wf_hit = reinterpret_cast<float *>(base); base += n * 16ull;
+                b.wf_state = reinterpret_cast<uint32_t *>(base); base += n * 16ull;
+                b.wf_chain = reinterpret_cast<uint32_t *>(base); base += n * 4ull * p.max_depth;
+                b.wf_stage = base;
+                b.wf_paths = (uint32_t)n;
+                b.wf_blocks = (uint32_t)((n + 63ull) / 64ull);
+                RTR_HIP_TRY(ctx, rtr::launch_wf_generate(b, b.sample_count, stream));
+                for (uint32_t d = 0; d < p.max_depth; d++) { // trace_ray's recursion levels (render.rs:32-36)
+                    b.wf_depth = d;
+                    RTR_HIP_TRY(ctx, rtr::launch_wf_intersect(b, std::min(wf_grid_i, b.wf_blocks), stream));
+                    RTR_HIP_TRY(ctx, rtr::launch_wf_shade(b, std::min(wf_grid_s, b.wf_blocks), stream));
+                }
+                p.wf_ray = b.wf_ray; // (for render_kernel_name below)
+            }
             if (last) RTR_HIP_TRY(ctx, hipEventRecord(ctx->ev_mid[slot], stream));
             RTR_HIP_TRY(ctx, rtr::launch_sum_samples(p.samples, b.sample_count, static_cast<float *>(ctx->d_carry), first, last, p.spp,
                                                      width * height, d_sum_rgba, d_rgba8, d_mean_rgb, stream));
@@ -334,7 +400,8 @@ int launch_frame(rtr_context *ctx, const rtr_camera *camera, const rtr_settings 
     ctx->launches++;
     {
         int vg = 0, sl = 0;
-        if (rtr::render_kernel_attributes(p, &vg, &sl) == hipSuccess) ctx->last_vgprs = (uint32_t)vg;
+        if (p.wf_ray ? rtr::wf_intersect_attributes(p, &vg) == hipSuccess : rtr::render_kernel_attributes(p, &vg, &sl) == hipSuccess)
+            ctx->last_vgprs = (uint32_t)vg;
     }
     ctx->kernel_name = rtr::render_kernel_name(p);
     return RTR_OK;
@@ -402,6 +469,7 @@ void rtr_destroy(rtr_context *ctx) {
         if (ctx->d_counters) (void)hipFree(ctx->d_counters);
         if (ctx->d_carry) (void)hipFree(ctx->d_carry);
         if (ctx->d_samples) (void)hipFree(ctx->d_samples);
+        if (ctx->d_wf) (void)hipFree(ctx->d_wf);
         if (ctx->d_chunk_flags) (void)hipFree(ctx->d_chunk_flags);
         if (ctx->d_rgba8) (void)hipFree(ctx->d_rgba8);
         if (ctx->d_mean) (void)hipFree(ctx->d_mean);
@@ -462,7 +530,15 @@ int rtr_set_option(rtr_context *ctx, const char *name, const char *value) {
         else if (v == "resumable") ctx->tree_kernel = 1;
         else if (v == "wave") ctx->tree_kernel = 2;
         else if (v == "samples") ctx->tree_kernel = 3;
-        else return fail(ctx, RTR_ERR_INVALID_ARGUMENT, "tree_kernel must be \"auto\", \"resumable\", \"wave\" or \"samples\"");
+        else if (v == "stream") ctx->tree_kernel = 4;
+        else return fail(ctx, RTR_ERR_INVALID_ARGUMENT, "tree_kernel must be \"auto\", \"stream\", \"samples\", \"resumable\" or \"wave\"");
+        return RTR_OK;
+    }
+    if (n == "stream_flush") { // takes effect at the next render
+        char *end = nullptr;
+        const unsigned long k = std::strtoul(v.c_str(), &end, 10);
+        if (v.empty() || *end != '\0' || k < 1ul || k > 64ul) return fail(ctx, RTR_ERR_INVALID_ARGUMENT, "stream_flush must be an integer in [1, 64]");
+        ctx->wf_flush = (uint32_t)k;
         return RTR_OK;
     }
     if (n == "samples_batch") { // takes effect at the next render; tests use it to force several batches

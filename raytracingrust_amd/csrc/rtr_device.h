@@ -122,6 +122,16 @@ struct RenderParams {
     uint32_t *chunk_flags;  // per launch-local tile: chunks completed (chunks > 1)
     unsigned long long chunk_timeout_ticks; // bound of a chunk's wait for its predecessor, in s_memrealtime ticks (100 MHz)
     unsigned long long *fault; // the context's sticky fault word: bit 0 = a chunk gave up waiting, bit 1 = "debug_fault"
+    // streaming wavefront path (tree worlds, option tree_kernel = "stream"): one record per path of a batch in HBM
+    float *wf_ray;        // 2 float4 per path: (o.xyz, d.x), (d.y, d.z, 0, 0)
+    float *wf_hit;        // float4 per path: t, u, v, leaf ref (bits); written by k_wf_intersect, read by k_wf_shade
+    uint32_t *wf_state;   // uint4 per path: rng state, rng inc, chain length, slot of the path's radiance in `samples`
+    uint32_t *wf_chain;   // [max_depth][wf_paths] material ids of the attenuation chain
+    uint8_t *wf_stage;    // per path: the depth at which it waits for intersect + shade; 255 = finished, or no such pixel
+    uint32_t wf_paths;    // paths of this batch: tiles * 64 * samples
+    uint32_t wf_blocks;   // ceil(wf_paths / 64): the unit waves scan
+    uint32_t wf_depth;    // the depth the launched kernel serves (trace_ray's `depth` argument, render.rs:32)
+    uint32_t wf_flush;    // k_wf_intersect: finished walks a wave collects before it stores them and refills the lanes
     // outputs
     float *sum_rgba;             // float4 per pixel (sharded path) or nullptr
     uint8_t *rgba8;              // fused path or nullptr

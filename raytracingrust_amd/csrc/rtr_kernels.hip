@@ -794,13 +794,29 @@ RTR_DEV V3 background(const RenderParams &p, const Ray &r) {
     return mk(texel.x, texel.y, texel.z);
 }
 
+// The attenuation chain of a path: the ids of the materials whose attenuation multiplies the terminal radiance, in
+// bounce order.  LdsChain: a per-lane column of the wave's LDS, [entry][lane] (conflict-free).  GlobalChain: one u32 per
+// (entry, path) in HBM, [entry][path], for the streaming kernels whose paths outlive a kernel.
+struct LdsChain {
+    uint32_t *base;
+    uint32_t lane, n;
+    RTR_DEV void push(uint32_t id) { base[n * 64u + lane] = id; n++; }
+    RTR_DEV uint32_t pop() { n--; return base[n * 64u + lane]; }
+};
+struct GlobalChain {
+    uint32_t *base;
+    uint64_t stride; // paths per entry row
+    uint32_t path, n;
+    RTR_DEV void push(uint32_t id) { base[(uint64_t)n * stride + path] = id; n++; }
+    RTR_DEV uint32_t pop() { n--; return base[(uint64_t)n * stride + path]; }
+};
+
 // attenuation * (attenuation * (... * terminal)) (render.rs:52), then f32::clamp(0, clamp_indirect) with NaN staying
 // NaN (render.rs:95-97): the radiance one finished sample adds to its pixel
-RTR_DEV V3 sample_radiance(const RenderParams &p, const uint32_t *lds_mats, const uint32_t *chain, uint32_t lane, uint32_t &nchain, V3 term) {
-    while (nchain > 0u) {
-        RTR_LS(24, true) RTR_LS1(23)
-        nchain--;
-        term = mul(material_rgb(p, lds_mats, chain[nchain * 64u + lane]), term);
+template <class Chain>
+RTR_DEV V3 sample_radiance(const RenderParams &p, const uint32_t *lds_mats, Chain &chain, V3 term) {
+    while (chain.n > 0u) {
+        term = mul(material_rgb(p, lds_mats, chain.pop()), term);
     }
     const float hi = p.clamp_indirect;
     if (term.x < 0.0f) term.x = 0.0f;
@@ -814,8 +830,10 @@ RTR_DEV V3 sample_radiance(const RenderParams &p, const uint32_t *lds_mats, cons
 
 // The part of trace_ray (render.rs:38-58) after world.hit: background on a miss, else the material's scatter.
 // Returns `done` (the path ended: `term` is its terminal radiance) or false with the next segment in `ray`.
+template <class Chain>
 RTR_DEV bool shade_segment(const RenderParams &p, bool was_hit, const Hit &h, Ray &ray, Rng &rng, const uint32_t *lds_mats,
-                           uint32_t *chain, uint32_t lane, uint32_t &nchain, uint32_t &depth, V3 &term) {
+                           Chain &chain, uint32_t lane, uint32_t &depth, V3 &term) {
+    (void)lane;
     bool done;
     RTR_LS(17, !was_hit)
     if (!was_hit) {
@@ -904,7 +922,7 @@ RTR_DEV bool shade_segment(const RenderParams &p, bool was_hit, const Hit &h, Ra
             ndir = sv;
         }
         if (scattered) {
-            if (mid != 0xFFFFFFFEu) { chain[nchain * 64u + lane] = mid; nchain++; }
+            if (mid != 0xFFFFFFFEu) chain.push(mid);
             ray.o = h.point;
             ray.d = ndir;
             depth++;
@@ -979,7 +997,8 @@ __global__ __launch_bounds__(64, RTR_X_WAVES_PER_EU) void k_render(const RenderP
     __builtin_amdgcn_s_waitcnt(0);
     __builtin_amdgcn_wave_barrier();
 #endif
-    uint32_t *chain = lds;
+    LdsChain chain;
+    chain.base = lds; chain.lane = lane; chain.n = 0u;
     uint32_t *stk_ref = lds + p.max_depth * 64u;
     float *stk_t = reinterpret_cast<float *>(stk_ref + p.stack_cap * 64u);
     uint32_t *lds_spheres = reinterpret_cast<uint32_t *>(stk_t + p.stack_cap * 64u);
@@ -1028,7 +1047,7 @@ __global__ __launch_bounds__(64, RTR_X_WAVES_PER_EU) void k_render(const RenderP
     const uint32_t s_first = p.sample_begin + chunk_boundary(p.sample_count, chunk, p.chunks, p.chunk_taper);
     const uint32_t s_last = p.sample_begin + chunk_boundary(p.sample_count, chunk + 1u, p.chunks, p.chunk_taper);
     const uint32_t spp = (inside && p.max_depth > 0u) ? s_last : s_first;
-    uint32_t s = s_first, depth = 0, nchain = 0;
+    uint32_t s = s_first, depth = 0;
     if (chunk > 0u) { // continue from the sums the previous chunk of this tile left behind
         chunk_wait(p, tidx, chunk);
         if (inside) {
@@ -1063,7 +1082,7 @@ __global__ __launch_bounds__(64, RTR_X_WAVES_PER_EU) void k_render(const RenderP
         // camera.rs:19-24
         ray.o = cam_o;
         ray.d = sub(sub(add(cam_llc, scale(cam_h, u)), scale(cam_v, v)), cam_o);
-        depth = 0; nchain = 0;
+        depth = 0; chain.n = 0u;
     };
     if (s < spp) start_sample(s);
 
@@ -1091,12 +1110,12 @@ __global__ __launch_bounds__(64, RTR_X_WAVES_PER_EU) void k_render(const RenderP
         V3 term;
         const bool was_hit = world_hit<WORLD, NS, VOL, MESH>(p, ray, h, stk_ref, stk_t, lane, sr, lds_spheres, rng);
         RTR_STAMP(0)
-        done = shade_segment(p, was_hit, h, ray, rng, lds_mats, chain, lane, nchain, depth, term);
+        done = shade_segment(p, was_hit, h, ray, rng, lds_mats, chain, lane, depth, term);
         RTR_STAMP(1)
         RTR_LS(21, done)
         if (done) {
             RTR_LS1(22)
-            acc = add(acc, sample_radiance(p, lds_mats, chain, lane, nchain, term)); // render.rs:99
+            acc = add(acc, sample_radiance(p, lds_mats, chain, term)); // render.rs:99
             s++;
             if (s < spp) start_sample(s);
         }
@@ -1181,7 +1200,8 @@ __global__ __launch_bounds__(64, RTR_X_BVH_WAVES) void k_render_bvh(const Render
     const uint32_t chunk = blockIdx.x / p.tiles_launch, tidx = blockIdx.x - chunk * p.tiles_launch;
     const uint32_t tile = tidx * p.n_shards + p.shard;
     if (tile >= p.tiles_total) return;
-    uint32_t *chain = lds;
+    LdsChain chain;
+    chain.base = lds; chain.lane = lane; chain.n = 0u;
     uint32_t *stk_ref = lds + p.max_depth * 64u;
     float *stk_t = reinterpret_cast<float *>(stk_ref + p.stack_cap * 64u);
     uint32_t *lds_mat_base = reinterpret_cast<uint32_t *>(stk_t + p.stack_cap * 64u);
@@ -1207,7 +1227,7 @@ __global__ __launch_bounds__(64, RTR_X_BVH_WAVES) void k_render_bvh(const Render
     const uint32_t s_first = p.sample_begin + chunk_boundary(p.sample_count, chunk, p.chunks, p.chunk_taper);
     const uint32_t s_last = p.sample_begin + chunk_boundary(p.sample_count, chunk + 1u, p.chunks, p.chunk_taper);
     const uint32_t spp = (inside && p.max_depth > 0u) ? s_last : s_first;
-    uint32_t s = s_first, depth = 0, nchain = 0;
+    uint32_t s = s_first, depth = 0;
     if (chunk > 0u) { // continue from the sums the previous chunk of this tile left behind
         chunk_wait(p, tidx, chunk);
         if (inside) {
@@ -1232,7 +1252,7 @@ __global__ __launch_bounds__(64, RTR_X_BVH_WAVES) void k_render_bvh(const Render
         }
         ray.o = cam_o;
         ray.d = sub(sub(add(cam_llc, scale(cam_h, u)), scale(cam_v, v)), cam_o);
-        depth = 0; nchain = 0;
+        depth = 0; chain.n = 0u;
     };
 
     // the walk's per-lane state (world_hit + traverse of k_render, unrolled into the loop below)
@@ -1279,9 +1299,9 @@ __global__ __launch_bounds__(64, RTR_X_BVH_WAVES) void k_render_bvh(const Render
             const bool was_hit = best.leaf != REF_NONE;
             if (was_hit) finish_leaf<VOL>(p, best, ray, h);
             V3 term;
-            const bool done = shade_segment(p, was_hit, h, ray, rng, lds_mats, chain, lane, nchain, depth, term);
+            const bool done = shade_segment(p, was_hit, h, ray, rng, lds_mats, chain, lane, depth, term);
             if (done) {
-                acc = add(acc, sample_radiance(p, lds_mats, chain, lane, nchain, term)); // render.rs:99
+                acc = add(acc, sample_radiance(p, lds_mats, chain, term)); // render.rs:99
                 s++;
                 if (s < spp) start_sample(s);
                 else alive = false;
@@ -1335,7 +1355,8 @@ __global__ __launch_bounds__(64, 6) void k_render_bvh_sp(const RenderParams p) {
     __builtin_amdgcn_s_waitcnt(0);
     __builtin_amdgcn_wave_barrier();
 #endif
-    uint32_t *chain = lds;
+    LdsChain chain;
+    chain.base = lds; chain.lane = lane; chain.n = 0u;
     uint32_t *stk_ref = lds + p.max_depth * 64u;
     float *stk_t = reinterpret_cast<float *>(stk_ref + p.stack_cap * 64u);
     uint32_t *lds_mat_base = reinterpret_cast<uint32_t *>(stk_t + p.stack_cap * 64u);
@@ -1358,7 +1379,7 @@ __global__ __launch_bounds__(64, 6) void k_render_bvh_sp(const RenderParams p) {
     const uint32_t s_last = p.sample_begin + chunk_boundary(p.sample_count, chunk + 1u, p.chunks, 0u);
     const uint32_t n_items = 64u * (s_last - s_first); // (sample, pixel) pairs of this workgroup, sample-major
     uint32_t next_item = 0;                            // wave-uniform
-    uint32_t depth = 0, nchain = 0;
+    uint32_t depth = 0;
     Ray ray;
     ray.o = cam_o; ray.d = cam_o;
     const SharedDiv div_w = shared_div_prepare(p.width_m1), div_h = shared_div_prepare(p.height_m1);
@@ -1376,7 +1397,7 @@ __global__ __launch_bounds__(64, 6) void k_render_bvh_sp(const RenderParams p) {
         }
         ray.o = cam_o;
         ray.d = sub(sub(add(cam_llc, scale(cam_h, u)), scale(cam_v, v)), cam_o);
-        depth = 0; nchain = 0;
+        depth = 0; chain.n = 0u;
     };
 
     // the walk's per-lane state (world_hit + traverse of k_render, unrolled into the loop below)
@@ -1454,9 +1475,9 @@ __global__ __launch_bounds__(64, 6) void k_render_bvh_sp(const RenderParams p) {
             const bool was_hit = best.leaf != REF_NONE;
             if (was_hit) finish_leaf<VOL>(p, best, ray, h);
             V3 term;
-            const bool done = shade_segment(p, was_hit, h, ray, rng, lds_mats, chain, lane, nchain, depth, term);
+            const bool done = shade_segment(p, was_hit, h, ray, rng, lds_mats, chain, lane, depth, term);
             if (done) { // the sample's clamped radiance (render.rs:95-97) goes to memory; k_sum_samples adds them in order
-                const V3 rad = sample_radiance(p, lds_mats, chain, lane, nchain, term);
+                const V3 rad = sample_radiance(p, lds_mats, chain, term);
                 reinterpret_cast<float4 *>(p.samples)[slot] = make_float4(rad.x, rad.y, rad.z, 0.0f);
                 alive = false;
                 need = true;
@@ -1477,6 +1498,217 @@ __global__ __launch_bounds__(64, 6) void k_render_bvh_sp(const RenderParams p) {
     if (lane == 0 && total) atomicAdd(p.counter, total);
 }
 
+
+// ---- WORLD_BVH, streaming wavefront: path state in HBM, one kernel per stage ---------------------------------------
+// The kernels above keep a path in one lane's registers from its first segment to its last, so a wave always holds a
+// mix of lanes that walk the tree and lanes that shade, regenerate or wait for the quorum: on house.obj 34 of 64 lanes
+// walk in an average trip (scripts/lanestat_tree.py), and the walk is nine tenths of the time.  Here the stages are
+// separate kernels and the paths of a batch of samples live in HBM between them (BASELINE's streaming design: SURVEY.md
+// section 8d prices it at ~100 B of path state per segment, which a tree walk of ~2500 lane-instructions can afford):
+//   k_wf_generate            every (sample, pixel) of the batch: camera ray, random stream (render.rs:80-90)
+//   per depth d = 0 .. max_ray_depth-1 (trace_ray's recursion level, render.rs:32-36):
+//     k_wf_intersect<d>      world.hit for every path alive at depth d.  A lane owns nothing: when its walk ends it
+//                            stores the hit and takes the next waiting path, so nearly every lane of every trip walks.
+//     k_wf_shade<d>          the rest of trace_ray for those paths: background / material / scatter; a path that ends
+//                            writes its sample's clamped radiance, one that goes on stores its next ray and moves to d+1.
+//   k_sum_samples            adds each pixel's samples in index order (as for k_render_bvh_sp).
+// A path is (sample, pixel); its random stream is keyed by both, and each path executes exactly the operations it
+// executes in k_render, in the same order: frames are bit-identical to the other tree kernels'.
+// No queues and no atomics: wf_stage[path] holds the depth a path waits at (255: finished).  A wave scans the stage
+// bytes of its blocks of 64 paths (block-cyclic over the grid), drops the ids that match the kernel's depth into a small
+// LDS ring and hands them to the lanes that ask.  Scanning costs one byte and a fraction of an instruction per path and
+// depth; the alternative, compacted queues, needs one returning atomic per appended run, and a single counter word
+// sustains ~88 of those per microsecond (MI355X_MICROARCH.md, dequeue) against ~13 M runs per 1080p frame.
+constexpr uint32_t kWfRing = 128u; // ids waiting in LDS: a block adds at most 64 to at most 63 left over
+
+struct WfScan {
+    uint32_t next_block, head, tail; // wave-uniform
+};
+// Scan blocks until the ring holds `want` ids or the wave's blocks are exhausted.  Returns the number of ids in the ring.
+RTR_DEV uint32_t wf_scan(const RenderParams &p, uint32_t depth, uint32_t lane, uint32_t *ring, WfScan &sc, uint32_t want) {
+    while (sc.head - sc.tail < want && sc.next_block < p.wf_blocks) {
+        const uint32_t id = sc.next_block * 64u + lane;
+        sc.next_block += gridDim.x;
+        const uint32_t stage = id < p.wf_paths ? (uint32_t)p.wf_stage[id] : 255u;
+        const bool mine = stage == depth;
+        const uint64_t m = __ballot(mine);
+        if (mine) ring[(sc.head + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))) & (kWfRing - 1u)] = id;
+        sc.head += (uint32_t)__popcll(m);
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f); // lgkmcnt(0): the ring entries are in LDS before any lane reads them
+    __builtin_amdgcn_wave_barrier();
+    return sc.head - sc.tail;
+}
+
+// render.rs:76-90 + camera.rs:19-24 for every (sample, pixel) of the batch.  grid = (tiles, samples of the batch), one
+// wave = one 8x8 tile of one sample, so the paths of a block start out as coherent as k_render's waves.
+__global__ __launch_bounds__(64) void k_wf_generate(const RenderParams p) {
+    const uint32_t lane = threadIdx.x;
+    const uint32_t tile = blockIdx.x, s_rel = blockIdx.y;
+    const uint32_t id = (s_rel * p.tiles_total + tile) * 64u + lane;
+    const uint32_t tx = tile % p.tiles_x, ty = tile / p.tiles_x;
+    const uint32_t x = tx * 8u + (lane & 7u), y = ty * 8u + (lane >> 3);
+    if (!(x < p.width && y < p.height)) { p.wf_stage[id] = 255u; return; }
+    const uint32_t pixel = y * p.width + x; // render.rs:76-77
+    const uint32_t hp = hash32(pixel ^ p.seed_key0);
+    Rng rng;
+    rng.inc = (hash32(hp + p.seed_key1) << 1) | 1u;
+    rng.state = hash32(hp + (p.sample_begin + s_rel) * 0x9E3779B9u);
+    float u = (float)x + rng_unit_inclusive(rng); // render.rs:88-89
+    float v = (float)y + rng_unit_inclusive(rng);
+    u = u / p.width_m1;
+    v = v / p.height_m1;
+    const V3 cam_o = ld3(p.cam_origin), cam_h = ld3(p.cam_horizontal), cam_v = ld3(p.cam_vertical), cam_llc = ld3(p.cam_llc);
+    const V3 d = sub(sub(add(cam_llc, scale(cam_h, u)), scale(cam_v, v)), cam_o); // camera.rs:19-24
+    float4 *ray = reinterpret_cast<float4 *>(p.wf_ray) + 2ull * id;
+    ray[0] = make_float4(cam_o.x, cam_o.y, cam_o.z, d.x);
+    ray[1] = make_float4(d.y, d.z, 0.0f, 0.0f);
+    reinterpret_cast<uint4 *>(p.wf_state)[id] = make_uint4(rng.state, rng.inc, 0u, s_rel * (p.width * p.height) + pixel);
+    p.wf_stage[id] = 0u;
+}
+
+// world.hit (render.rs:38) for every path waiting at depth p.wf_depth.  LDS: [stack refs: cap x 64][stack t: cap x 64][ring]
+#ifndef RTR_X_WF_WAVES
+#define RTR_X_WF_WAVES 6
+#endif
+template <bool VOL, bool MESH>
+__global__ __launch_bounds__(64, RTR_X_WF_WAVES) void k_wf_intersect(const RenderParams p) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const uint32_t lane = threadIdx.x;
+    uint32_t *stk_ref = lds;
+    float *stk_t = reinterpret_cast<float *>(stk_ref + p.stack_cap * 64u);
+    uint32_t *ring = reinterpret_cast<uint32_t *>(stk_t + p.stack_cap * 64u);
+    const uint32_t depth = p.wf_depth;
+    WfScan sc;
+    sc.next_block = blockIdx.x; sc.head = 0u; sc.tail = 0u;
+
+    // the walk's per-lane state
+    uint32_t id = 0u, cur = REF_NONE, sp = 0u, nseg = 0u;
+    Best best;
+    best_reset(best);
+    Ray ray;
+    ray.o = mk(0.0f, 0.0f, 0.0f); ray.d = ray.o;
+    V3 inv = ray.o;
+    float a = 0.0f;
+    Rng rng;
+    rng.state = 0u; rng.inc = 1u;
+    bool walking = false; // the lane's walk is in progress
+    bool holding = false; // the lane's walk has ended and its hit is not stored yet
+    for (;;) {
+        // ---- lanes without a path take the next waiting ones ----
+        {
+            const uint64_t asking = __ballot(!walking && !holding);
+            if (asking != 0ull) {
+                const uint32_t want = (uint32_t)__popcll(asking);
+                const uint32_t have = wf_scan(p, depth, lane, ring, sc, want);
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(asking >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)asking, 0u));
+                if (!walking && !holding && rank < have) {
+                    id = ring[(sc.tail + rank) & (kWfRing - 1u)];
+                    const float4 *rq = reinterpret_cast<const float4 *>(p.wf_ray) + 2ull * id;
+                    const float4 r0 = rq[0], r1 = rq[1];
+                    ray.o = mk(r0.x, r0.y, r0.z);
+                    ray.d = mk(r0.w, r1.x, r1.y);
+                    if constexpr (VOL) { // Volume::hit draws from the path's stream inside world.hit (volume.rs:57)
+                        const uint2 rs = *reinterpret_cast<const uint2 *>(p.wf_state + 4ull * id);
+                        rng.state = rs.x; rng.inc = rs.y;
+                    }
+                    // the head of world_hit<WORLD_BVH>
+                    nseg++;
+                    a = dot(ray.d, ray.d);
+                    inv = mk(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z);
+                    best_reset(best);
+                    const uint32_t root = p.root_ref;
+                    bool go = root != REF_NONE;
+                    if (go && (root & (REF_LEAF | REF_PAIR)) != REF_LEAF) {
+                        float e;
+                        go = slab(p.root_box, p.root_box + 3, ray, inv, __builtin_inff(), e);
+                    }
+                    cur = root; sp = 0u;
+                    walking = go;
+                    holding = !go;
+                }
+                sc.tail += want < have ? want : have;
+            }
+        }
+        const uint64_t walkers = __ballot(walking);
+        if (walkers == 0ull && __ballot(holding) == 0ull) break; // nothing in flight and nothing left to take
+        // ---- walk: kWalkUnroll trips for every lane with a walk in progress ----
+        if (walkers != 0ull) {
+#pragma unroll
+            for (uint32_t rep = 0; rep < kWalkUnroll; rep++)
+                if (walking) RTR_WALK_TRIP(ray, __builtin_inff(), { walking = false; holding = true; })
+        }
+        // ---- finished walks are stored together, once enough of them wait (or nothing else is left to do) ----
+        const uint64_t held = __ballot(holding);
+        if (held != 0ull && ((uint32_t)__popcll(held) >= p.wf_flush || __ballot(walking) == 0ull)) {
+            if (holding) {
+                reinterpret_cast<float4 *>(p.wf_hit)[id] = make_float4(best.t, best.u, best.v, __uint_as_float(best.leaf));
+                if constexpr (VOL) p.wf_state[4ull * id] = rng.state;
+                holding = false;
+            }
+        }
+    }
+    unsigned long long total = nseg;
+    for (int off = 32; off > 0; off >>= 1) total += __shfl_xor(total, off, 64);
+    if (lane == 0 && total) atomicAdd(p.counter, total);
+}
+
+// The rest of trace_ray (render.rs:39-58) for every path waiting at depth p.wf_depth, full waves of them at a time.
+// LDS: [ring][materials: lds_mats x 8]
+template <bool VOL>
+__global__ __launch_bounds__(64) void k_wf_shade(const RenderParams p) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const uint32_t lane = threadIdx.x;
+    uint32_t *ring = lds;
+    uint32_t *lds_mat_base = lds + kWfRing;
+    const uint32_t *lds_mats = p.lds_materials ? lds_mat_base : nullptr;
+    if (p.lds_materials)
+        for (uint32_t i = lane; i < p.lds_materials * 8u; i += 64u) lds_mat_base[i] = reinterpret_cast<const uint32_t *>(p.materials)[i];
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t depth0 = p.wf_depth;
+    WfScan sc;
+    sc.next_block = blockIdx.x; sc.head = 0u; sc.tail = 0u;
+    for (;;) {
+        const uint32_t have = wf_scan(p, depth0, lane, ring, sc, 64u);
+        if (have == 0u) break;
+        const uint32_t take = have < 64u ? have : 64u;
+        if (lane < take) {
+            const uint32_t id = ring[(sc.tail + lane) & (kWfRing - 1u)];
+            const float4 *rq = reinterpret_cast<const float4 *>(p.wf_ray) + 2ull * id;
+            const float4 r0 = rq[0], r1 = rq[1];
+            const float4 hq = reinterpret_cast<const float4 *>(p.wf_hit)[id];
+            const uint4 st = reinterpret_cast<const uint4 *>(p.wf_state)[id];
+            Ray ray;
+            ray.o = mk(r0.x, r0.y, r0.z);
+            ray.d = mk(r0.w, r1.x, r1.y);
+            Best best;
+            best.t = hq.x; best.u = hq.y; best.v = hq.z; best.leaf = __float_as_uint(hq.w); best.cull = 0.0f;
+            Rng rng;
+            rng.state = st.x; rng.inc = st.y;
+            GlobalChain chain;
+            chain.base = p.wf_chain; chain.stride = p.wf_paths; chain.path = id; chain.n = st.z;
+            uint32_t depth = depth0;
+            Hit h;
+            const bool was_hit = best.leaf != REF_NONE;
+            if (was_hit) finish_leaf<VOL>(p, best, ray, h);
+            V3 term;
+            const bool done = shade_segment(p, was_hit, h, ray, rng, lds_mats, chain, lane, depth, term);
+            if (done) { // the sample's clamped radiance (render.rs:95-97); k_sum_samples adds a pixel's samples in order
+                const V3 rad = sample_radiance(p, lds_mats, chain, term);
+                reinterpret_cast<float4 *>(p.samples)[st.w] = make_float4(rad.x, rad.y, rad.z, 0.0f);
+                p.wf_stage[id] = 255u;
+            } else {
+                float4 *wq = reinterpret_cast<float4 *>(p.wf_ray) + 2ull * id;
+                wq[0] = make_float4(ray.o.x, ray.o.y, ray.o.z, ray.d.x);
+                wq[1] = make_float4(ray.d.y, ray.d.z, 0.0f, 0.0f);
+                *reinterpret_cast<uint4 *>(p.wf_state + 4ull * id) = make_uint4(rng.state, rng.inc, chain.n, st.w);
+                p.wf_stage[id] = (uint8_t)(depth0 + 1u);
+            }
+        }
+        sc.tail += take;
+    }
+}
 
 // Adds each pixel's samples in index order (render.rs:99) and finishes the pixel (render.rs:103-110), or stores the sum.
 // A launch's samples may arrive in several batches (the buffer is bounded): `acc_io` carries the running sums from one
@@ -1629,6 +1861,47 @@ hipError_t launch_render(const RenderParams &p, uint32_t grid, uint32_t lds_byte
     return hipGetLastError();
 }
 
+hipError_t launch_wf_generate(const RenderParams &p, uint32_t batch_samples, hipStream_t stream) {
+    hipLaunchKernelGGL(k_wf_generate, dim3(p.tiles_total, batch_samples), dim3(64), 0, stream, p);
+    return hipGetLastError();
+}
+static const void *wf_intersect_kernel(const RenderParams &p) {
+    return p.has_volumes ? (p.has_meshes ? reinterpret_cast<const void *>(k_wf_intersect<true, true>) : reinterpret_cast<const void *>(k_wf_intersect<true, false>))
+                         : (p.has_meshes ? reinterpret_cast<const void *>(k_wf_intersect<false, true>) : reinterpret_cast<const void *>(k_wf_intersect<false, false>));
+}
+uint32_t wf_intersect_lds_bytes(const RenderParams &p) { return (2u * p.stack_cap * 64u + kWfRing) * 4u; }
+uint32_t wf_shade_lds_bytes(const RenderParams &p) { return (kWfRing + p.lds_materials * 8u) * 4u; }
+// workgroups (one wave each) of k_wf_intersect / k_wf_shade the device keeps resident
+uint32_t wf_resident_waves(const RenderParams &p, bool shade) {
+    int per_cu = 0, dev = 0, cus = 0;
+    const void *fn = shade ? (p.has_volumes ? reinterpret_cast<const void *>(k_wf_shade<true>) : reinterpret_cast<const void *>(k_wf_shade<false>))
+                           : wf_intersect_kernel(p);
+    const uint32_t lds = shade ? wf_shade_lds_bytes(p) : wf_intersect_lds_bytes(p);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 64, lds) != hipSuccess || per_cu <= 0) per_cu = 16;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    return (uint32_t)per_cu * (uint32_t)cus;
+}
+hipError_t launch_wf_intersect(const RenderParams &p, uint32_t grid, hipStream_t stream) {
+    const uint32_t lds = wf_intersect_lds_bytes(p);
+    if (p.has_volumes && p.has_meshes) hipLaunchKernelGGL((k_wf_intersect<true, true>), dim3(grid), dim3(64), lds, stream, p);
+    else if (p.has_volumes) hipLaunchKernelGGL((k_wf_intersect<true, false>), dim3(grid), dim3(64), lds, stream, p);
+    else if (p.has_meshes) hipLaunchKernelGGL((k_wf_intersect<false, true>), dim3(grid), dim3(64), lds, stream, p);
+    else hipLaunchKernelGGL((k_wf_intersect<false, false>), dim3(grid), dim3(64), lds, stream, p);
+    return hipGetLastError();
+}
+hipError_t launch_wf_shade(const RenderParams &p, uint32_t grid, hipStream_t stream) {
+    const uint32_t lds = wf_shade_lds_bytes(p);
+    if (p.has_volumes) hipLaunchKernelGGL((k_wf_shade<true>), dim3(grid), dim3(64), lds, stream, p);
+    else hipLaunchKernelGGL((k_wf_shade<false>), dim3(grid), dim3(64), lds, stream, p);
+    return hipGetLastError();
+}
+hipError_t wf_intersect_attributes(const RenderParams &p, int *vgprs) {
+    hipFuncAttributes attr;
+    hipError_t e = hipFuncGetAttributes(&attr, wf_intersect_kernel(p));
+    if (e == hipSuccess) *vgprs = attr.numRegs;
+    return e;
+}
+
 hipError_t launch_sum_samples(const float *samples, uint32_t n_samples, float *acc_io, bool first_batch, bool last_batch, uint32_t spp,
                               uint32_t n_pixels, float *sum_rgba, uint8_t *rgba8, float *mean_rgb, hipStream_t stream) {
     hipLaunchKernelGGL(k_sum_samples, dim3((n_pixels + 255u) / 256u), dim3(256), 0, stream, samples, n_samples, acc_io,
@@ -1665,6 +1938,7 @@ hipError_t render_kernel_attributes(const RenderParams &p, int *vgprs, int *stat
 
 // the name rocprofv3 prints for the kernel launch_render would take (bench.py's roofline.kernel)
 const char *render_kernel_name(const RenderParams &p) {
+    if (p.world == WORLD_BVH && p.wf_ray) return "rtr::k_wf_intersect (tree world, streaming wavefront: paths in HBM) + rtr::k_wf_generate / k_wf_shade / k_sum_samples";
     if (p.world == WORLD_BVH && p.sample_parallel) return "rtr::k_render_bvh_sp (tree world, lanes take samples) + rtr::k_sum_samples";
     if (p.world == WORLD_BVH && p.resumable_walk) return "rtr::k_render_bvh (tree world, resumable walk)";
     if (p.world == WORLD_BVH) return "rtr::k_render<WORLD_BVH> (tree world, wave-synchronous walk)";

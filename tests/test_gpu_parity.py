@@ -523,21 +523,22 @@ def _tiny_tree_scene(n):
                                          (lambda: _tiny_tree_scene(0), 40, 24), (lambda: _tiny_tree_scene(1), 40, 24),
                                          (lambda: _tiny_tree_scene(2), 40, 24), (lambda: _tiny_tree_scene(3), 40, 24)])
 def test_tree_kernels_agree_bit_for_bit(builder, w, h):
-    """Option tree_kernel: the wave-synchronous walk (k_render) and the resumable per-lane walk (k_render_bvh) execute
-    the same operations per lane in the same order, so their frames must be identical to the last bit -- and equal the
-    oracle's."""
+    """Option tree_kernel: the wave-synchronous walk (k_render), the resumable per-lane walk (k_render_bvh), the
+    sample-parallel walk (k_render_bvh_sp) and the streaming wavefront (k_wf_*: paths in device memory, one kernel per
+    stage and depth) execute the same operations per path in the same order, so their frames must be identical to the
+    last bit -- and equal the oracle's."""
     scene = builder()
     frames = {}
     with rt.Renderer(0) as r:
         r.upload_scene(scene)
-        for kernel in ("wave", "resumable", "auto", "samples"):
+        for kernel in ("wave", "resumable", "auto", "samples", "stream"):
             r.set_option("tree_kernel", kernel)
             rgba, mean = r.render(w, h, seed=77, want_rgba8=True, want_mean=True)
             frames[kernel] = (rgba, mean.view(np.uint32).copy(), r.stats().segments)
         with pytest.raises(rt.RtrError):
             r.set_option("tree_kernel", "fast")
-    for kernel in ("resumable", "auto", "samples"):
-        assert frames[kernel][2] == frames["wave"][2]
+    for kernel in ("resumable", "auto", "samples", "stream"):
+        assert frames[kernel][2] == frames["wave"][2], kernel
         assert np.array_equal(frames[kernel][0], frames["wave"][0]) and np.array_equal(frames[kernel][1], frames["wave"][1])
     o_rgba, o_mean, o_st = pyoracle.OracleScene(scene, trig_mode=pyoracle.TRIG_POLY).render(w, h, 77, threads=0)
     assert o_st.segments == frames["wave"][2]
@@ -596,7 +597,7 @@ def test_sample_chunks_in_the_sharded_paths(gpu_renderer):
 
 
 def test_sample_parallel_kernel_in_batches_and_sample_shards(gpu_renderer):
-    """tree_kernel = "samples": per-sample radiance goes through device memory and is added per pixel in index order.
+    """tree_kernel = "samples" / "stream": per-sample radiance goes through device memory and is added per pixel in index order.
     The sample-sharded launches (what a rank of the multi-GPU path runs) must give the same float4 sums as the resumable
     kernel, bit for bit, also when the sample range does not start at 0 and with several chunks."""
     import torch
@@ -609,7 +610,7 @@ def test_sample_parallel_kernel_in_batches_and_sample_shards(gpu_renderer):
     out = {}
     try:
         for kernel, chunks, batch in (("resumable", "1", "0"), ("samples", "auto", "0"), ("samples", "5", "0"), ("samples", "2", "3"),
-                                      ("samples", "auto", "1")):
+                                      ("samples", "auto", "1"), ("stream", "auto", "0"), ("stream", "auto", "3"), ("stream", "auto", "1")):
             r.set_option("tree_kernel", kernel)
             r.set_option("sample_chunks", chunks)
             r.set_option("samples_batch", batch)

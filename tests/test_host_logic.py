@@ -264,7 +264,8 @@ def test_options_are_validated_without_a_device():
     RTR_ERR_INVALID_ARGUMENT; tree options change the flattened tree, kernel options do not."""
     with rt.Renderer(-1) as r:
         for name, good, bad in [("mesh_tree", ["reference", "sah"], "octree"), ("scene_tree", ["sah", "reference"], ""),
-                                ("leaf_pairs", ["off", "on"], "maybe"), ("tree_kernel", ["wave", "resumable", "samples", "auto"], "fast"),
+                                ("leaf_pairs", ["off", "on"], "maybe"), ("tree_kernel", ["wave", "resumable", "samples", "stream", "auto"], "fast"),
+                                ("stream_flush", ["1", "64", "8"], "0"),
                                 ("samples_batch", ["3", "0"], "-1"),
                                 ("sample_chunks", ["1", "7", "auto"], "0"),
                                 ("chunk_timeout_ms", ["0", "2.5", "10000"], "-1"), ("debug_fault", ["on", "off"], "1")]:
