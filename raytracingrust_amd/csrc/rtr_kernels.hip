@@ -335,6 +335,21 @@ RTR_DEV void gather_fence(const float4 &a, const float4 &b, const float4 &c, con
                  "v"(d.x), "v"(d.y), "v"(d.z), "v"(d.w));
 }
 
+// Entry distances on the traversal stack.  They are read back for one purpose: to skip a deferred box that the best hit
+// has overtaken meanwhile (`e > best.cull`).  Any value not above the true entry distance keeps that test exact -- it can
+// only fail to skip, and the box's children are then tested against the best hit anyway -- so the stack keeps the upper
+// 16 bits of the f32 (truncation: toward zero, and entries are +0, positive, or -inf for "never skip").  Six bytes per
+// entry instead of eight: LDS per wave is what limits the tree kernels' occupancy (house.obj: 17 -> 23 waves per CU).
+#ifndef RTR_X_STACK_F32
+typedef uint16_t StackT;
+RTR_DEV StackT stack_t_pack(float e) { return (StackT)(__float_as_uint(e) >> 16); }
+RTR_DEV float stack_t_unpack(StackT h) { return __uint_as_float((uint32_t)h << 16); }
+#else
+typedef float StackT;
+RTR_DEV StackT stack_t_pack(float e) { return e; }
+RTR_DEV float stack_t_unpack(StackT h) { return h; }
+#endif
+
 struct Best {
     float t, u, v;
     uint32_t leaf; // REF_LEAF|type|L, or REF_NONE
@@ -464,7 +479,7 @@ RTR_DEV void test_leaf(const RenderParams &p, uint32_t ref, const Ray &r, float 
                 if (sw_ ? lvol_ : rvol_) esecond_ = -__builtin_inff(); /* never culled at pop time */                    \
                 cur = sw_ ? r_ : l_;                                                                                     \
                 stk_ref[sp * 64 + lane] = second_;                                                                       \
-                stk_t[sp * 64 + lane] = esecond_;                                                                        \
+                stk_t[sp * 64 + lane] = stack_t_pack(esecond_);                                                                      \
                 sp++;                                                                                                    \
             } else if (hl_) {                                                                                            \
                 cur = l_;                                                                                                \
@@ -481,7 +496,7 @@ RTR_DEV void test_leaf(const RenderParams &p, uint32_t ref, const Ray &r, float 
                 RTR_LS1(9) RTR_LS(10, true)                                                                              \
                 sp--;                                                                                                    \
                 const uint32_t c_ = stk_ref[sp * 64 + lane];                                                             \
-                const float e_ = stk_t[sp * 64 + lane];                                                                  \
+                const float e_ = stack_t_unpack(stk_t[sp * 64 + lane]);                                                                \
                 if (e_ > best.cull) continue; /* its box is entered beyond the best hit (never for -inf entries) */      \
                 cur = c_;                                                                                                \
                 got_ = true;                                                                                             \
@@ -495,7 +510,7 @@ RTR_DEV void test_leaf(const RenderParams &p, uint32_t ref, const Ray &r, float 
 // form (the wave returns when its slowest lane has finished).
 template <bool VOL, bool MESH>
 RTR_DEV void traverse(const RenderParams &p, uint32_t root, const Ray &r, V3 inv, float a, float tmax_box,
-                      Best &best, uint32_t *stk_ref, float *stk_t, uint32_t lane, Rng &rng) {
+                      Best &best, uint32_t *stk_ref, StackT *stk_t, uint32_t lane, Rng &rng) {
     uint32_t sp = 0;
     uint32_t cur = root;
     bool walking = true;
@@ -553,7 +568,7 @@ struct SphereRegs {
 
 // world.hit (render.rs:38).  Returns false on miss.
 template <uint32_t WORLD, uint32_t NS, bool VOL, bool MESH>
-RTR_DEV bool world_hit(const RenderParams &p, const Ray &r, Hit &h, uint32_t *stk_ref, float *stk_t, uint32_t lane,
+RTR_DEV bool world_hit(const RenderParams &p, const Ray &r, Hit &h, uint32_t *stk_ref, StackT *stk_t, uint32_t lane,
                        const SphereRegs<NS> &sr, const uint32_t *lds_spheres, Rng &rng) {
     const float a = dot(r.d, r.d); // objects.rs:25, hoisted per ray
     if constexpr (WORLD == WORLD_LINEAR_SPHERES && NS > 0) {
@@ -1000,7 +1015,7 @@ __global__ __launch_bounds__(64, RTR_X_WAVES_PER_EU) void k_render(const RenderP
     LdsChain chain;
     chain.base = lds; chain.lane = lane; chain.n = 0u;
     uint32_t *stk_ref = lds + p.max_depth * 64u;
-    float *stk_t = reinterpret_cast<float *>(stk_ref + p.stack_cap * 64u);
+    StackT *stk_t = reinterpret_cast<StackT *>(stk_ref + p.stack_cap * 64u);
     uint32_t *lds_spheres = reinterpret_cast<uint32_t *>(stk_t + p.stack_cap * 64u);
     uint32_t *lds_mat_base = lds_spheres + NS * 8u;
     const uint32_t *lds_mats = p.lds_materials ? lds_mat_base : nullptr;
@@ -1203,7 +1218,7 @@ __global__ __launch_bounds__(64, RTR_X_BVH_WAVES) void k_render_bvh(const Render
     LdsChain chain;
     chain.base = lds; chain.lane = lane; chain.n = 0u;
     uint32_t *stk_ref = lds + p.max_depth * 64u;
-    float *stk_t = reinterpret_cast<float *>(stk_ref + p.stack_cap * 64u);
+    StackT *stk_t = reinterpret_cast<StackT *>(stk_ref + p.stack_cap * 64u);
     uint32_t *lds_mat_base = reinterpret_cast<uint32_t *>(stk_t + p.stack_cap * 64u);
     const uint32_t *lds_mats = p.lds_materials ? lds_mat_base : nullptr;
     if (p.lds_materials)
@@ -1358,7 +1373,7 @@ __global__ __launch_bounds__(64, 6) void k_render_bvh_sp(const RenderParams p) {
     LdsChain chain;
     chain.base = lds; chain.lane = lane; chain.n = 0u;
     uint32_t *stk_ref = lds + p.max_depth * 64u;
-    float *stk_t = reinterpret_cast<float *>(stk_ref + p.stack_cap * 64u);
+    StackT *stk_t = reinterpret_cast<StackT *>(stk_ref + p.stack_cap * 64u);
     uint32_t *lds_mat_base = reinterpret_cast<uint32_t *>(stk_t + p.stack_cap * 64u);
     const uint32_t *lds_mats = p.lds_materials ? lds_mat_base : nullptr;
     if (p.lds_materials)
@@ -1576,7 +1591,7 @@ __global__ __launch_bounds__(64, RTR_X_WF_WAVES) void k_wf_intersect(const Rende
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const uint32_t lane = threadIdx.x;
     uint32_t *stk_ref = lds;
-    float *stk_t = reinterpret_cast<float *>(stk_ref + p.stack_cap * 64u);
+    StackT *stk_t = reinterpret_cast<StackT *>(stk_ref + p.stack_cap * 64u);
     uint32_t *ring = reinterpret_cast<uint32_t *>(stk_t + p.stack_cap * 64u);
     const uint32_t depth = p.wf_depth;
     WfScan sc;
@@ -1869,7 +1884,8 @@ static const void *wf_intersect_kernel(const RenderParams &p) {
     return p.has_volumes ? (p.has_meshes ? reinterpret_cast<const void *>(k_wf_intersect<true, true>) : reinterpret_cast<const void *>(k_wf_intersect<true, false>))
                          : (p.has_meshes ? reinterpret_cast<const void *>(k_wf_intersect<false, true>) : reinterpret_cast<const void *>(k_wf_intersect<false, false>));
 }
-uint32_t wf_intersect_lds_bytes(const RenderParams &p) { return (2u * p.stack_cap * 64u + kWfRing) * 4u; }
+uint32_t wf_intersect_lds_bytes(const RenderParams &p) { return p.stack_cap * 64u * (4u + (uint32_t)sizeof(StackT)) + kWfRing * 4u; }
+uint32_t stack_entry_bytes() { return 4u + (uint32_t)sizeof(StackT); }
 uint32_t wf_shade_lds_bytes(const RenderParams &p) { return (kWfRing + p.lds_materials * 8u) * 4u; }
 // workgroups (one wave each) of k_wf_intersect / k_wf_shade the device keeps resident
 uint32_t wf_resident_waves(const RenderParams &p, bool shade) {
