@@ -36,6 +36,7 @@ hipError_t launch_wf_shade(const RenderParams &p, uint32_t grid, hipStream_t str
 uint32_t wf_resident_waves(const RenderParams &p, bool shade);
 uint32_t wf_intersect_lds_bytes(const RenderParams &p);
 uint32_t stack_entry_bytes();
+uint32_t coop_ball_lds_bytes();
 hipError_t wf_intersect_attributes(const RenderParams &p, int *vgprs);
 hipError_t launch_selftest_div(float d, uint32_t lo_bits, uint32_t hi_bits, unsigned long long *d_mismatches, hipStream_t stream);
 } // namespace rtr
@@ -258,6 +259,9 @@ int launch_frame(rtr_context *ctx, const rtr_camera *camera, const rtr_settings 
     p.lds_materials = (p.n_materials > 0u && p.n_materials <= lds_mat_cap) ? p.n_materials : 0u;
     // dynamic LDS per wave: attenuation chain + traversal stack (refs + entry distances) + the tables
     uint32_t lds_bytes = p.max_depth * 64u * 4u + p.stack_cap * 64u * rtr::stack_entry_bytes() + (p.sphere_regs + p.lds_materials) * 32u;
+#ifdef RTR_X_COOP_BALL
+    if (p.sphere_regs) lds_bytes += rtr::coop_ball_lds_bytes(); // the wave-cooperative rejection sampler's scratch (experiment)
+#endif
     if (lds_bytes > 160u * 1024u) return fail(ctx, RTR_ERR_UNSUPPORTED, "max_ray_depth + tree height exceed one CU's LDS");
     ctx->last_lds = lds_bytes;
     ctx->last_primary = 0;

@@ -843,32 +843,116 @@ RTR_DEV V3 sample_radiance(const RenderParams &p, const uint32_t *lds_mats, Chai
     return term;
 }
 
+// --- the rejection sampler, wave-cooperative -------------------------------------------------------------------------
+// In the headline kernel the plain loop of sample_unit_ball is the most divergent block there is: 25 of a wave's lanes
+// enter it in an average trip, the wave iterates until its unluckiest lane has an accepted candidate (5.5 times), and
+// 11 lanes are active in an average iteration (scripts/lanestat.py).  All the candidates those lanes need -- 1.9 each --
+// fit into ONE pass of the 64 lanes.  Candidate k of a call is a closed-form function of the call's seed word r and k
+// (the LCG sub-stream, jump-ahead by 3k states), so any lane can evaluate it:
+//   round 0   every lane that needs a sample tests its own candidate 0 (no communication);
+//   round j   the n lanes still without a sample publish their sub-stream state in LDS; lane L evaluates candidate
+//             L / n of requester L % n (each requester gets 64 / n candidates at once, lanes that need nothing
+//             included); an LDS atomic min per requester finds its FIRST accepted candidate, whose lane writes the point
+//             back; a requester left without one advances its state past the candidates tried and goes round again.
+// The accepted point is the one the serial loop would have accepted, bit for bit (same state sequence, same test), and
+// the path's own stream advanced by one word before the first round, as in sample_unit_ball.  Must be called by ALL lanes
+// of the wave (`need` false for lanes that want nothing).  LDS: kCoopWords u32 per wave.
+struct CoopBall {
+    uint32_t *lds; // [list: 64 x (state, first accepted k)][results: 64 x float4][jump: 64 x (A^(3k), C_(3k))]
+};
+constexpr uint32_t kCoopWords = 64u * 2u + 64u * 4u + 64u * 2u;
+RTR_DEV void coop_ball_init(const CoopBall &cb, uint32_t lane) { // jump table: state after 3k steps = s * A3k + C3k
+    uint32_t am = 1u, cm = 0u;
+    for (uint32_t i = 0; i < 3u * lane; i++) { cm = cm * kBallMul + kBallInc; am = am * kBallMul; }
+    cb.lds[64u * 6u + lane * 2u] = am;
+    cb.lds[64u * 6u + lane * 2u + 1u] = cm;
+}
+RTR_DEV V3 coop_ball(const CoopBall &cb, bool need, Rng &rng, uint32_t lane, float &m2) {
+    uint2 *list = reinterpret_cast<uint2 *>(cb.lds);
+    float4 *res = reinterpret_cast<float4 *>(cb.lds + 128u);
+    const uint2 *jump = reinterpret_cast<const uint2 *>(cb.lds + 384u);
+    V3 v = mk(0.0f, 0.0f, 0.0f);
+    m2 = 1.0f;
+    uint32_t s = 0u;
+    bool pending = false;
+    if (need) { // round 0: the lane's own candidate 0
+        s = rng_u32(rng);
+        v.x = ball_coord(s); v.y = ball_coord(s); v.z = ball_coord(s);
+        m2 = dot(v, v);
+        pending = !(m2 <= 1.0f);
+    }
+    const float lane_f = (float)lane + 0.5f;
+    for (;;) {
+        const uint64_t pend = __ballot(pending);
+        if (pend == 0ull) break;
+        const uint32_t n = (uint32_t)__popcll(pend);
+        const uint32_t rho = __builtin_amdgcn_mbcnt_hi((uint32_t)(pend >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pend, 0u));
+        if (pending) list[rho] = make_uint2(s, 0xFFFFFFFFu);
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // lane L serves requester q = L % n with candidate kk = L / n: (L + 0.5) / n is never within rounding of an integer
+        const float inv_n = __builtin_amdgcn_rcpf((float)n); // 1 ulp is plenty: the quotients below stay 1/128 away from an integer
+        const uint32_t kk = (uint32_t)(lane_f * inv_n);
+        const uint32_t q = lane - kk * n;
+        const uint2 jk = jump[kk];
+        uint32_t t = list[q].x * jk.x + jk.y;
+        V3 c;
+        c.x = ball_coord(t); c.y = ball_coord(t); c.z = ball_coord(t);
+        const float cm2 = dot(c, c);
+        const bool ok = cm2 <= 1.0f;
+        if (ok) atomicMin(&list[q].y, kk);
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (ok && list[q].y == kk) res[q] = make_float4(c.x, c.y, c.z, cm2);
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (pending) {
+            if (list[rho].y != 0xFFFFFFFFu) {
+                const float4 r = res[rho];
+                v = mk(r.x, r.y, r.z); m2 = r.w;
+                pending = false;
+            } else { // candidates 0 .. K-1 of this round all rejected: K = lanes L with L % n == rho
+                const uint32_t kdone = (uint32_t)((63.5f - (float)rho) * inv_n) + 1u;
+                const uint2 jd = jump[kdone & 63u];
+                s = kdone < 64u ? s * jd.x + jd.y : s; // (kdone == 64: n == 1, handled below)
+                if (kdone >= 64u) { for (uint32_t i = 0; i < 192u; i++) s = s * kBallMul + kBallInc; }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    return v;
+}
+
 // The part of trace_ray (render.rs:38-58) after world.hit: background on a miss, else the material's scatter.
 // Returns `done` (the path ended: `term` is its terminal radiance) or false with the next segment in `ray`.
-template <class Chain>
+// COOP: the wave-cooperative form of the rejection sampler; the function must then be called by every lane of the wave,
+// with `active` false for the lanes that have no segment to shade (they take part in the sampler's rounds only).
+template <bool COOP = false, class Chain>
 RTR_DEV bool shade_segment(const RenderParams &p, bool was_hit, const Hit &h, Ray &ray, Rng &rng, const uint32_t *lds_mats,
-                           Chain &chain, uint32_t lane, uint32_t &depth, V3 &term) {
-    (void)lane;
-    bool done;
-    RTR_LS(17, !was_hit)
-    if (!was_hit) {
-        term = background(p, ray);
-        done = true;
-    } else if (p.mode == 3u) { // RenderMode::Normal, render.rs:42-45
-        V3 n = scale(add(normalize(h.normal), mk(1.0f, 1.0f, 1.0f)), 0.5f);
-        term = n;
-        done = true;
-    } else if (p.mode == 2u) { // RenderMode::Random, render.rs:46-48
-        term = mk(0.0f, 0.0f, 0.0f);
-        done = true;
-    } else {
-        uint32_t kind, mid = h.material;
-        float param = 0.0f;
-        V3 rgb = mk(0.8f, 0.8f, 0.8f);
-        if (p.mode == 1u) { // RenderMode::Clay: Lambertian(0.8) (render.rs:41)
+                           Chain &chain, uint32_t lane, uint32_t &depth, V3 &term, bool active = true, const CoopBall *coop = nullptr) {
+    (void)lane; (void)coop;
+    bool done = false;
+    uint32_t kind = 7u, mid = 0u; // 7: no material to scatter from (inactive lane, miss, or a mode that returns at once)
+    float param = 0.0f;
+    V3 rgb = mk(0.8f, 0.8f, 0.8f);
+    RTR_LS(17, active && !was_hit)
+    if (active) {
+        if (!was_hit) {
+            term = background(p, ray);
+            done = true;
+        } else if (p.mode == 3u) { // RenderMode::Normal, render.rs:42-45
+            V3 n = scale(add(normalize(h.normal), mk(1.0f, 1.0f, 1.0f)), 0.5f);
+            term = n;
+            done = true;
+        } else if (p.mode == 2u) { // RenderMode::Random, render.rs:46-48
+            term = mk(0.0f, 0.0f, 0.0f);
+            done = true;
+        } else if (p.mode == 1u) { // RenderMode::Clay: Lambertian(0.8) (render.rs:41)
             kind = 0u; mid = kChainClay;
         } else {
             // MixMaterial::scatter (materials.rs:148-157): xi >= factor -> first
+            mid = h.material;
             for (;;) {
                 float4 q0, q1;
                 material_load(p, lds_mats, mid, q0, q1);
@@ -879,27 +963,45 @@ RTR_DEV bool shade_segment(const RenderParams &p, bool was_hit, const Hit &h, Ra
                 mid = (rng_unit(rng) >= param) ? __float_as_uint(q1.y) : __float_as_uint(q1.z);
             }
         }
+    }
+    // Lambertian, Metal and Isotropic all start from one rejection-sampled point of the unit ball
+    // (sample.rs:43-51) and it is their first draw after the mix walk, so the sampler is run ONCE for all
+    // three kinds (one divergent block per segment instead of one per material kind).
+    V3 sv = mk(0.0f, 0.0f, 0.0f);
+    RTR_LS(13, kind == 0u) RTR_LS(14, kind == 1u) RTR_LS(15, kind == 2u) RTR_LS(16, kind == 3u)
+    const bool need_ball = kind == 0u || kind == 1u || kind == 5u;
+    float m2 = 1.0f;
+#ifdef RTR_X_COOP_PLAIN // diagnostic: the cooperative kernel's loop structure with the plain sampler
+    if constexpr (COOP) { if (need_ball) sv = sample_unit_ball(rng, m2); } else
+#endif
+    if constexpr (COOP) {
+        sv = coop_ball(*coop, need_ball, rng, lane, m2);
+    } else if (need_ball) {
+#ifdef RTR_X_LANESTAT
+        RTR_LS1(20)
+        uint32_t bs = rng_u32(rng);
+        do {
+            RTR_LS(19, true) RTR_LS1(18)
+            sv.x = ball_coord(bs); sv.y = ball_coord(bs); sv.z = ball_coord(bs);
+            m2 = dot(sv, sv);
+        } while (!(m2 <= 1.0f));
+#else
+        sv = sample_unit_ball(rng, m2);
+#endif
+    }
+    if (kind != 7u) {
         bool scattered = true;
         V3 ndir = h.normal;
-        // Lambertian, Metal and Isotropic all start from one rejection-sampled point of the unit ball
-        // (sample.rs:43-51) and it is their first draw after the mix walk, so the loop is run ONCE for all
-        // three kinds (one divergent loop per segment instead of one per material kind).
-        V3 sv = mk(0.0f, 0.0f, 0.0f);
-        RTR_LS(13, kind == 0u) RTR_LS(14, kind == 1u) RTR_LS(15, kind == 2u) RTR_LS(16, kind == 3u)
-        if (kind == 0u || kind == 1u || kind == 5u) {
-            float m2;
-#ifdef RTR_X_LANESTAT
-            RTR_LS1(20)
-            uint32_t bs = rng_u32(rng);
-            do {
-                RTR_LS(19, true) RTR_LS1(18)
-                sv.x = ball_coord(bs); sv.y = ball_coord(bs); sv.z = ball_coord(bs);
-                m2 = dot(sv, sv);
-            } while (!(m2 <= 1.0f));
-#else
-            sv = sample_unit_ball(rng, m2);
-#endif
-            if (kind != 5u) sv = scale(sv, 1.0f / rt_sqrt(m2)); // sample_unit_sphere_surface, sample.rs:66-70
+        // One pass of `v * (1 / |v|)` (cgmath normalize) for every kind that normalises a vector first: the ball sample of
+        // Lambertian and Metal (sample_unit_sphere_surface, sample.rs:66-70) and the ray direction of Dielectric
+        // (materials.rs:116).  Same operations per lane; one block for ~34 lanes instead of two for 25 and 9.
+        V3 unit = mk(0.0f, 0.0f, 0.0f);
+        if (kind == 0u || kind == 1u || kind == 3u) {
+            const bool di = kind == 3u;
+            const V3 x = di ? ray.d : sv;
+            const float x2 = di ? dot(ray.d, ray.d) : m2;
+            unit = scale(x, 1.0f / rt_sqrt(x2));
+            if (!di) sv = unit;
         }
         if (kind == 0u) { // Lambertian, materials.rs:31-41
             ndir = add(h.normal, sv);
@@ -911,26 +1013,17 @@ RTR_DEV bool shade_segment(const RenderParams &p, bool was_hit, const Hit &h, Ra
         } else if (kind == 2u) { // Emission, materials.rs:86-91
             scattered = false; term = rgb;
         } else if (kind == 3u) { // Dielectric, materials.rs:111-138
-#ifndef RTR_X_NO_DIELECTRIC_CONSTANTS
             // 1/ir and the two Schlick r0^2 values are constants of the material, divided once on the host
             // (rtr_scene.cpp) into the record's spare words: re-read here rather than kept live across the sampler
             float4 dq0, dq1;
             material_load(p, lds_mats, mid, dq0, dq1);
             const float ratio = h.front_face ? dq1.y : param;
             const float r0sq = h.front_face ? dq1.z : dq1.w;
-#else
-            float ratio = h.front_face ? 1.0f / param : param;
-#endif
-            V3 unit = normalize(ray.d);
             float cos_theta = fminf(dot(h.normal, neg(unit)), 1.0f);
             float sin_theta = rt_sqrt(1.0f - cos_theta * cos_theta);
             bool cannot_refract = (ratio * sin_theta) > 1.0f;
             bool refl = cannot_refract;
-#ifndef RTR_X_NO_DIELECTRIC_CONSTANTS
             if (!refl) refl = reflectance_r0(cos_theta, r0sq) > rng_unit(rng); // no draw on TIR (short-circuit ||)
-#else
-            if (!refl) refl = reflectance(cos_theta, ratio) > rng_unit(rng); // no draw on TIR (short-circuit ||)
-#endif
             ndir = refl ? reflect(unit, h.normal) : refract(unit, h.normal, ratio);
             mid = 0xFFFFFFFEu; // attenuation (1,1,1): x*1 == x exactly, nothing to replay
         } else { // Isotropic, volume.rs:80-88: the un-normalised ball sample is the direction
@@ -1112,6 +1205,42 @@ __global__ __launch_bounds__(64, RTR_X_WAVES_PER_EU) void k_render(const RenderP
 #else
 #define RTR_STAMP(k)
 #endif
+    // Measured on the headline frame (1080p, 256 spp; MI355X, round 2), bit-identical frames in every case: plain
+    // loop 15.3 ms; this kernel's every-lane-stays loop with the plain sampler 15.9 ms; with the cooperative sampler
+    // 16.3 ms (70 VGPRs; capped to 64: 16.4 ms).  A round is ~45 vector instructions -- two iterations of the plain loop,
+    // as planned -- but its four dependent LDS round trips and the restructured loop cost more than the 3-4 saved
+    // iterations bring.  Kept for the record behind -DRTR_X_COOP_BALL, not in the product.
+#ifdef RTR_X_COOP_BALL
+    constexpr bool COOP = WORLD == WORLD_LINEAR_SPHERES && NS > 0;
+#else
+    constexpr bool COOP = false;
+#endif
+    if constexpr (COOP) {
+        // Every lane stays in the loop until the wave's last path has ended: the rejection sampler inside shade_segment is
+        // wave-cooperative, and a lane that has run out of samples still evaluates candidates for the others.
+        CoopBall cb;
+        cb.lds = lds_mat_base + p.lds_materials * 8u;
+        coop_ball_init(cb, lane);
+        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_wave_barrier();
+        for (;;) {
+            const bool alive = s < spp;
+            if (__ballot(alive) == 0ull) break;
+            Hit h;
+            bool was_hit = false;
+            if (alive) {
+                nseg++;
+                was_hit = world_hit<WORLD, NS, VOL, MESH>(p, ray, h, stk_ref, stk_t, lane, sr, lds_spheres, rng);
+            }
+            V3 term;
+            const bool done = shade_segment<true>(p, was_hit, h, ray, rng, lds_mats, chain, lane, depth, term, alive, &cb);
+            if (alive && done) {
+                acc = add(acc, sample_radiance(p, lds_mats, chain, term)); // render.rs:99
+                s++;
+                if (s < spp) start_sample(s);
+            }
+        }
+    } else
     while (s < spp) {
         RTR_STAMP(4)
         RTR_LS(1, true) RTR_LS1(0)
@@ -1886,6 +2015,7 @@ static const void *wf_intersect_kernel(const RenderParams &p) {
 }
 uint32_t wf_intersect_lds_bytes(const RenderParams &p) { return p.stack_cap * 64u * (4u + (uint32_t)sizeof(StackT)) + kWfRing * 4u; }
 uint32_t stack_entry_bytes() { return 4u + (uint32_t)sizeof(StackT); }
+uint32_t coop_ball_lds_bytes() { return kCoopWords * 4u; }
 uint32_t wf_shade_lds_bytes(const RenderParams &p) { return (kWfRing + p.lds_materials * 8u) * 4u; }
 // workgroups (one wave each) of k_wf_intersect / k_wf_shade the device keeps resident
 uint32_t wf_resident_waves(const RenderParams &p, bool shade) {
