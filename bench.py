@@ -70,7 +70,9 @@ def parse_args(argv=None):
                     help="mesh subtrees: the reference's median split (parity) or the binned-SAH rebuild (faster walk)")
     ap.add_argument("--scene-tree", choices=["reference", "sah"], default="reference",
                     help="scene-level tree over the objects: the reference's median split (parity) or binned SAH")
-    ap.add_argument("--tree-kernel", default=None, help="rtr_set_option tree_kernel (auto, wave, resumable, samples, pool)")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="headline run only: skip the short secondary measurements of BASELINE's tree configurations")
+    ap.add_argument("--tree-kernel", default=None, help="rtr_set_option tree_kernel (auto, stream, samples, resumable, wave)")
     return ap.parse_args(argv)
 
 
@@ -233,6 +235,33 @@ def cpu_baseline(scene, width, height, spp_sample, seed):
     return rec, rgba, spp_sample, int(st.segments)
 
 
+def other_configs(r, torch, dev, stream, seed):
+    """Short secondary measurements, reported beside the headline so that the driver's record carries them too:
+    BASELINE's tree-world configurations (C1 simple.json, C3 monkey + HDRI, C4 house + plane + HDRI) at 1920x1080 and 256
+    spp, one warm-up frame and two timed frames each through the same device-resident entry point.  Flat scalars."""
+    from raytracingrust_amd.configs import baseline_config
+
+    out = {}
+    for name in ("c1", "c3", "c4"):
+        scene, W, H = baseline_config(name, 256)
+        r.upload_scene(scene)
+        rgba8 = torch.zeros((H, W, 4), dtype=torch.uint8, device=dev)
+        r.render_frame_device(W, H, seed, rgba8.data_ptr(), stream)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(2):
+            r.render_frame_device(W, H, seed + 1 + i, rgba8.data_ptr(), stream)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 2.0
+        seg = float(r.segment_counts()[-2:].mean())
+        out[name + "_mrays_per_s"] = round(seg / dt / 1e6, 1)
+        out[name + "_ms_per_frame"] = round(dt * 1e3, 3)
+        out[name + "_segments_per_frame"] = int(seg)
+    out["note"] = ("1920x1080, 256 spp, reference (median-split) trees, tree_kernel auto; C1 simple.json 102 spheres, C3 monkey.obj + "
+                   "plane + synthetic HDRI, C4 house.obj + plane + synthetic HDRI depth 3; full lines: python bench.py --config cN")
+    return out
+
+
 def main():
     args = parse_args()
     world_env = os.environ.get("WORLD_SIZE")
@@ -391,6 +420,9 @@ def main():
             out["config"]["parity_full_frame_detail"] = (
                 f"{W}x{H} at {o_spp} spp, seed {args.seed:#x}: {bad_px} of {W * H} RGBA8 pixels differ (max channel "
                 f"difference {max_diff}); segments GPU {g_segments} vs oracle {o_segments}")
+        headline = not args.config and not args.bvh and (W, H, args.spp) == (1920, 1080, 256) and os.path.basename(args.scene) == "benchmark.json"
+        if headline and world == 1 and not args.no_other_configs:
+            out["other_configs"] = other_configs(r, torch, dev, stream, args.seed)
         print(json.dumps(out), flush=True)
     r.close()
     if distributed:

@@ -67,6 +67,7 @@ struct Lowered {
     std::vector<rtr_mesh> meshes;
     std::vector<rtr_material> materials;
     std::vector<rtr_volume> volumes;
+    std::vector<rtr_mesh> boundary_meshes; // meshes that only bound a Volume: appended behind the objects' meshes by Scene::lower
     rtr_background background{};
     rtr_scene_desc desc() const {
         rtr_scene_desc d{};
@@ -183,24 +184,6 @@ class Sphere : public Object { // objects.rs:15-20
     }
 };
 
-class Volume : public Object { // volume.rs:19-32 (sphere boundaries on the GPU path)
-  public:
-    Volume(Sphere boundary, float density) : boundary(std::move(boundary)), neg_inv_density(-1.0f / density) {}
-    Sphere boundary; float neg_inv_density;
-    MaterialHandle material() const override { return boundary.material(); } // volume.rs:98-100
-    void lower(Lowered &out) const override {
-        rtr_volume v{};
-        v.boundary.center[0] = boundary.center.x; v.boundary.center[1] = boundary.center.y; v.boundary.center[2] = boundary.center.z;
-        v.boundary.radius = boundary.radius; v.boundary.material = (uint32_t)boundary.mat.index;
-        v.neg_inv_density = neg_inv_density;
-        out.objects.push_back(rtr_object{RTR_OBJ_VOLUME, (uint32_t)out.volumes.size()});
-        out.volumes.push_back(v);
-    }
-    std::string to_json() const override {
-        return "{\"type\": \"Volume\", \"boundary\": " + boundary.to_json() + ", \"neg_inv_density\": " + jsonw::num(neg_inv_density) + "}";
-    }
-};
-
 // The subset of obj-rs 0.7 load_obj::<obj::Vertex,u32> the reference uses (mesh.rs:63-66): triangulated faces with
 // normals; one vertex per distinct (position index, normal index) pair in first-appearance order.
 inline void load_obj(const std::string &path, std::vector<float> &positions, std::vector<float> &normals, std::vector<uint32_t> &indices) {
@@ -265,6 +248,38 @@ class Mesh : public Object { // mesh.rs:31-121
         out.meshes.push_back(m);
     }
     std::string to_json() const override { throw std::runtime_error("Mesh cannot be serialized (the reference panics: mesh.rs:40-49)"); }
+};
+
+class Volume : public Object { // volume.rs:19-32: `boundary: Box<dyn Object>` -- a Sphere or a Mesh here
+  public:
+    Volume(Sphere boundary, float density) : sphere(std::move(boundary)), neg_inv_density(-1.0f / density) {}
+    Volume(std::unique_ptr<Mesh> boundary, float density) : sphere(Vec3{0, 0, 0}, 0.0f, boundary->mat), mesh(std::move(boundary)), neg_inv_density(-1.0f / density) {}
+    Sphere sphere;              // the boundary when mesh is null
+    std::unique_ptr<Mesh> mesh; // the boundary otherwise
+    float neg_inv_density;
+    MaterialHandle material() const override { return mesh ? mesh->material() : sphere.material(); } // volume.rs:98-100
+    void lower(Lowered &out) const override {
+        rtr_volume v{};
+        if (mesh) {
+            rtr_mesh m{};
+            m.positions = mesh->positions.data(); m.normals = mesh->normals.data(); m.indices = mesh->indices.data();
+            m.n_verts = (uint32_t)(mesh->positions.size() / 3); m.n_tris = (uint32_t)(mesh->indices.size() / 3); m.material = (uint32_t)mesh->mat.index;
+            v.boundary.material = m.material;
+            v.boundary_kind = RTR_OBJ_MESH;
+            v.boundary_mesh = (uint32_t)out.boundary_meshes.size(); // rebased by Scene::lower
+            out.boundary_meshes.push_back(m);
+        } else {
+            v.boundary.center[0] = sphere.center.x; v.boundary.center[1] = sphere.center.y; v.boundary.center[2] = sphere.center.z;
+            v.boundary.radius = sphere.radius; v.boundary.material = (uint32_t)sphere.mat.index;
+        }
+        v.neg_inv_density = neg_inv_density;
+        out.objects.push_back(rtr_object{RTR_OBJ_VOLUME, (uint32_t)out.volumes.size()});
+        out.volumes.push_back(v);
+    }
+    std::string to_json() const override {
+        if (mesh) throw std::runtime_error("a Volume over a Mesh cannot be serialized (Mesh panics in the reference: mesh.rs:40-49)");
+        return "{\"type\": \"Volume\", \"boundary\": " + sphere.to_json() + ", \"neg_inv_density\": " + jsonw::num(neg_inv_density) + "}";
+    }
 };
 
 // ---- backgrounds (lib/backgrounds.rs) ------------------------------------------------------------------------
@@ -459,6 +474,12 @@ class Scene {
         out.materials.resize(materials_.size());
         for (size_t i = 0; i < materials_.size(); i++) materials_[i]->lower(out.materials, i);
         for (auto &o : objects) o->lower(out);
+        // meshes that bound a Volume follow the objects' meshes (the order raytracingrust_amd/scene.py uses too)
+        const uint32_t n_object_meshes = (uint32_t)out.meshes.size();
+        for (auto &v : out.volumes)
+            if (v.boundary_kind == RTR_OBJ_MESH) v.boundary_mesh += n_object_meshes;
+        out.meshes.insert(out.meshes.end(), out.boundary_meshes.begin(), out.boundary_meshes.end());
+        out.boundary_meshes.clear();
         background->lower(out.background);
     }
 

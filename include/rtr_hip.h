@@ -45,7 +45,7 @@ extern "C" {
 #endif
 
 /* 2: volumes, rtr_set_option.  3: rtr_selftest_div, options "leaf_pairs"; structs unchanged since 2. */
-#define RTR_ABI_VERSION 3
+#define RTR_ABI_VERSION 4
 
 typedef enum rtr_status {
     RTR_OK = 0,
@@ -94,12 +94,17 @@ typedef struct rtr_mesh {
     uint32_t reserved;
 } rtr_mesh;
 
-/* Volume, lib/volume.rs:19-32: a constant-density medium inside a boundary object.  The GPU path accepts
- * sphere boundaries (the boundary's material is the medium's, normally Isotropic); a mesh boundary is
- * RTR_ERR_UNSUPPORTED.  The boundary sphere is NOT listed in objects[] itself. */
+/* Volume, lib/volume.rs:19-32: a constant-density medium inside a boundary object (`boundary: Box<dyn Object>`).
+ * boundary_kind = RTR_OBJ_SPHERE: `boundary` is the sphere.  boundary_kind = RTR_OBJ_MESH (ABI revision 4):
+ * meshes[boundary_mesh] is the boundary; Volume::hit then makes its two boundary.hit calls (volume.rs:35-36) through
+ * that mesh's own tree with the ranges [-inf, +inf] and [t1 + tmin, +inf] -- Triangle::hit takes the lower bound as its
+ * determinant epsilon too (mesh.rs:166,190), which is reproduced.  The boundary's material is the medium's (normally
+ * Isotropic).  A boundary sphere or mesh is NOT listed in objects[] itself. */
 typedef struct rtr_volume {
     rtr_sphere boundary;
     float neg_inv_density; /* -1/density, as Volume::new stores it (volume.rs:29) */
+    uint32_t boundary_kind; /* RTR_OBJ_SPHERE (0) | RTR_OBJ_MESH (1) */
+    uint32_t boundary_mesh; /* index into meshes[] when boundary_kind = RTR_OBJ_MESH */
 } rtr_volume;
 
 typedef struct rtr_material {

@@ -51,6 +51,7 @@ def lib():
         L.or_add_sphere.argtypes = [C.c_void_p, _f3, C.c_float, C.c_int]
         L.or_add_mesh.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_int]
         L.or_add_volume_sphere.argtypes = [C.c_void_p, _f3, C.c_float, C.c_int, C.c_float]
+        L.or_add_volume_mesh.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_int, C.c_float]
         L.or_render.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64, C.c_int, C.c_uint32, C.c_uint32,
                                 C.c_void_p, C.c_void_p, C.POINTER(or_stats)]
         L.or_camera_ray_origin.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
@@ -123,8 +124,14 @@ class OracleScene:
                                           remap.get(o.material, o.material)))
             elif isinstance(o, S.Volume):
                 b = o.boundary
-                self._check(L.or_add_volume_sphere(self._s, f3(b.center), float(np.float32(b.radius)),
-                                                   remap.get(b.material, b.material), float(np.float32(o.density))))
+                if isinstance(b, S.Mesh):
+                    self._check(L.or_add_volume_mesh(self._s, b.positions.ctypes.data_as(C.c_void_p),
+                                                     b.normals.ctypes.data_as(C.c_void_p), b.positions.shape[0],
+                                                     b.indices.ctypes.data_as(C.c_void_p), b.n_tris,
+                                                     remap.get(b.material, b.material), float(np.float32(o.density))))
+                else:
+                    self._check(L.or_add_volume_sphere(self._s, f3(b.center), float(np.float32(b.radius)),
+                                                       remap.get(b.material, b.material), float(np.float32(o.density))))
             else:
                 raise TypeError(o)
 

@@ -206,7 +206,9 @@ typedef struct {                                                    /* mesh.rs:3
     bvh_node *bvh_root;
     int material;
 } mesh_t;
-typedef struct { sphere_t boundary; float neg_inv_density; } volume_t; /* volume.rs:19-23 */
+/* volume.rs:19-23: `boundary: Box<dyn Object>` -- a sphere, or a mesh (boundary_mesh != NULL; the mesh's material is the
+ * medium's, Object::material of Mesh) */
+typedef struct { sphere_t boundary; mesh_t *boundary_mesh; float neg_inv_density; } volume_t;
 
 enum { OBJ_SPHERE = 0, OBJ_MESH = 1, OBJ_VOLUME = 2 };
 typedef struct { int kind; sphere_t sphere; mesh_t *mesh; volume_t volume; } object_t;
@@ -318,7 +320,7 @@ static aabb_t coll_bounds(const collection *c, uint32_t handle) {
     switch (o->kind) {
     case OBJ_SPHERE: return sphere_bounds(&o->sphere);
     case OBJ_MESH: return o->mesh->bounds;                        /* mesh.rs:234-238 */
-    default: return sphere_bounds(&o->volume.boundary);           /* volume.rs:90-94 */
+    default: return o->volume.boundary_mesh ? o->volume.boundary_mesh->bounds : sphere_bounds(&o->volume.boundary); /* volume.rs:90-94 */
     }
 }
 static int coll_hit(const collection *c, uint32_t handle, const ray_t *ray, float tmin, float tmax, hit_t *out,
@@ -410,11 +412,20 @@ static int bvh_hit(const bvh_node *n, const ray_t *ray, float tmin, float tmax, 
 }
 
 static inline float or_log(float x, int mode);
-/* lib/volume.rs:34-73  Volume::hit (boundary restricted to a sphere here) */
+/* self.boundary.hit(ray, tmin, tmax) for the two kinds of boundary a Volume is built over here (volume.rs:35-36) */
+static int volume_boundary_hit(const volume_t *v, const ray_t *ray, float tmin, float tmax, hit_t *out, tctx_t *tc) {
+    if (v->boundary_mesh) { /* Mesh::hit, mesh.rs:124-127: the mesh's own tree with the caller's range; Triangle::hit
+                             * takes tmin as its determinant epsilon and its lower bound on t, and ignores tmax */
+        collection c = {NULL, v->boundary_mesh};
+        return bvh_hit(v->boundary_mesh->bvh_root, ray, tmin, tmax, &c, out, tc);
+    }
+    return sphere_hit(&v->boundary, ray, tmin, tmax, out, tc);
+}
+/* lib/volume.rs:34-73  Volume::hit */
 static int volume_hit(const volume_t *v, const ray_t *ray, float tmin, float tmax, hit_t *out, tctx_t *tc, int trig_mode) {
     hit_t hit1, hit2;
-    if (!sphere_hit(&v->boundary, ray, -INFINITY, INFINITY, &hit1, tc)) return 0;
-    if (!sphere_hit(&v->boundary, ray, hit1.t + tmin, INFINITY, &hit2, tc)) return 0;
+    if (!volume_boundary_hit(v, ray, -INFINITY, INFINITY, &hit1, tc)) return 0;
+    if (!volume_boundary_hit(v, ray, hit1.t + tmin, INFINITY, &hit2, tc)) return 0;
     if (hit1.t < tmin) hit1.t = tmin;
     if (hit2.t > tmax) hit2.t = tmax;
     if (hit1.t >= hit2.t) return 0;
@@ -425,7 +436,7 @@ static int volume_hit(const volume_t *v, const ray_t *ray, float tmin, float tma
     float hit_distance = v->neg_inv_density * or_log(random_float, trig_mode);
     if (hit_distance > distance_inside_boundary) return 0;
     float t = hit1.t + hit_distance / ray_length;
-    *out = hit_new(ray_at(ray, t), v3_new(1.0f, 0.0f, 0.0f), t, ray, v->boundary.material);
+    *out = hit_new(ray_at(ray, t), v3_new(1.0f, 0.0f, 0.0f), t, ray, v->boundary_mesh ? v->boundary_mesh->material : v->boundary.material);
     return 1;
 }
 
@@ -786,7 +797,7 @@ static bvh_node *scene_build_bvh(const or_scene *s, int *err) { /* scene.rs:112-
 static int validate(const or_scene *s) {
     for (int i = 0; i < s->n_objects; i++) {
         const object_t *o = &s->objects[i];
-        int m = o->kind == OBJ_SPHERE ? o->sphere.material : (o->kind == OBJ_MESH ? o->mesh->material : o->volume.boundary.material);
+        int m = o->kind == OBJ_SPHERE ? o->sphere.material : (o->kind == OBJ_MESH ? o->mesh->material : (o->volume.boundary_mesh ? o->volume.boundary_mesh->material : o->volume.boundary.material));
         if (m < 0 || m >= s->n_materials) return or_fail(-3, "material index out of bounds (scene.rs:106-110 would panic)");
     }
     if (!(s->clamp_indirect == s->clamp_indirect) || s->clamp_indirect < 0.0f)
@@ -864,7 +875,10 @@ static void mesh_free(mesh_t *m) {
 }
 void or_scene_free(or_scene *s) {
     if (!s) return;
-    for (int i = 0; i < s->n_objects; i++) if (s->objects[i].kind == OBJ_MESH) mesh_free(s->objects[i].mesh);
+    for (int i = 0; i < s->n_objects; i++) {
+        if (s->objects[i].kind == OBJ_MESH) mesh_free(s->objects[i].mesh);
+        if (s->objects[i].kind == OBJ_VOLUME && s->objects[i].volume.boundary_mesh) mesh_free(s->objects[i].volume.boundary_mesh);
+    }
     free(s->objects); free(s->materials); free(s->sky); free(s);
 }
 void or_set_camera(or_scene *s, const float lookfrom[3], const float lookat[3], const float vertical[3],
@@ -926,10 +940,11 @@ int or_add_volume_sphere(or_scene *s, const float c[3], float radius, int materi
     o->volume.neg_inv_density = -1.0f / density; /* volume.rs:26-31 */
     return s->n_objects - 1;
 }
-int or_add_mesh(or_scene *s, const float *positions, const float *normals, uint32_t n_verts, const uint32_t *indices,
-                uint32_t n_tris, int material) {
+/* Mesh::from_buffers + build_bvh (mesh.rs:78-121); NULL (with the error set) on failure */
+static mesh_t *mesh_build(const float *positions, const float *normals, uint32_t n_verts, const uint32_t *indices,
+                          uint32_t n_tris, int material) {
     for (uint32_t i = 0; i < 3 * n_tris; i++)
-        if (indices[i] >= n_verts) return or_fail(-8, "vertex index out of bounds (mesh.rs:84-88 would panic)");
+        if (indices[i] >= n_verts) { or_fail(-8, "vertex index out of bounds (mesh.rs:84-88 would panic)"); return NULL; }
     mesh_t *m = (mesh_t *)calloc(1, sizeof *m);
     m->n_verts = n_verts; m->n_tris = n_tris; m->material = material;
     m->vertices = (vertex_t *)malloc((size_t)(n_verts ? n_verts : 1) * sizeof *m->vertices);
@@ -955,9 +970,26 @@ int or_add_mesh(or_scene *s, const float *positions, const float *normals, uint3
     int err = 0;
     m->bvh_root = bvh_from_list(objs, (int)n_tris, &c, &err);
     free(objs);
-    if (err) { mesh_free(m); return or_fail(-2, "NaN centroid in mesh BVH build"); }
+    if (err) { mesh_free(m); or_fail(-2, "NaN centroid in mesh BVH build"); return NULL; }
+    return m;
+}
+int or_add_mesh(or_scene *s, const float *positions, const float *normals, uint32_t n_verts, const uint32_t *indices,
+                uint32_t n_tris, int material) {
+    mesh_t *m = mesh_build(positions, normals, n_verts, indices, n_tris, material);
+    if (!m) return -1;
     object_t *o = push_object(s);
     o->kind = OBJ_MESH; o->mesh = m;
+    return s->n_objects - 1;
+}
+/* Volume::new(Box::new(mesh), density), volume.rs:25-32 */
+int or_add_volume_mesh(or_scene *s, const float *positions, const float *normals, uint32_t n_verts, const uint32_t *indices,
+                       uint32_t n_tris, int material, float density) {
+    mesh_t *m = mesh_build(positions, normals, n_verts, indices, n_tris, material);
+    if (!m) return -1;
+    object_t *o = push_object(s);
+    o->kind = OBJ_VOLUME;
+    o->volume.boundary_mesh = m;
+    o->volume.neg_inv_density = -1.0f / density;
     return s->n_objects - 1;
 }
 

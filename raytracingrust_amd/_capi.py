@@ -21,7 +21,8 @@ class rtr_mesh(C.Structure):
 
 
 class rtr_volume(C.Structure):
-    _fields_ = [("boundary", rtr_sphere), ("neg_inv_density", C.c_float)]
+    _fields_ = [("boundary", rtr_sphere), ("neg_inv_density", C.c_float), ("boundary_kind", C.c_uint32),
+                ("boundary_mesh", C.c_uint32)]
 
 
 class rtr_material(C.Structure):

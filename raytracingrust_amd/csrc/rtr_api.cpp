@@ -208,7 +208,7 @@ int launch_frame(rtr_context *ctx, const rtr_camera *camera, const rtr_settings 
     else if (fs.spheres_only) { p.world = rtr::WORLD_LINEAR_SPHERES; p.stack_cap = 0u; }
     else { p.world = rtr::WORLD_LINEAR_GENERIC; p.stack_cap = fs.mesh_stack_depth + 1u; }
     p.n_objects = fs.n_objects;
-    p.has_volumes = fs.has_volumes ? 1u : 0u;
+    p.has_volumes = fs.has_volumes ? (fs.has_mesh_volumes ? 2u : 1u) : 0u; // 2: the kernels with the nested mesh walk
     // "auto": the resumable walk (k_render_bvh) for scenes with meshes.  Measured against the wave-synchronous
     // k_render<BVH>: +45 % on house.obj, +10 % on monkey.obj; on sphere-only trees equal within 2 % (reference trees)
     // or 7 % behind (SAH trees), so those keep k_render.

@@ -99,7 +99,8 @@ struct RenderParams {
     uint32_t has_meshes;    // the scene holds triangles: tree kernels instantiated with the unconditional slab tests
     uint32_t sample_parallel; // WORLD_BVH: k_render_bvh_sp + k_sum_samples
     uint32_t resumable_walk; // WORLD_BVH: k_render_bvh (per-lane walk state machine) instead of k_render
-    uint32_t has_volumes;   // the scene holds Volume objects: kernels instantiated with the visit-order rules
+    uint32_t has_volumes;   // 0: no Volume objects; 1: sphere-bounded ones (kernels instantiated with the visit-order rules);
+                            // 2: mesh-bounded ones too (those kernels plus the nested mesh walk of Volume::hit)
     const DevNode *nodes;
     const DevLeafHot *leaf_hot;
     const DevLeafCold *leaf_cold;

@@ -287,12 +287,9 @@ RTR_DEV float poly_log(float xx) {
     return z;
 }
 
-// Volume::hit (lib/volume.rs:34-73) over a sphere boundary.  Draws one random number per call -- after both
-// boundary hits succeeded and the clipped interval is non-empty -- exactly where the reference draws it.
-RTR_DEV bool volume_t(V3 c, float r2, float neg_inv_density, const Ray &r, float a, float tmax, Rng &rng, float &t) {
-    float t1, t2;
-    if (!sphere_range(c, r2, r, a, -__builtin_inff(), __builtin_inff(), t1)) return false;
-    if (!sphere_range(c, r2, r, a, t1 + kTMin, __builtin_inff(), t2)) return false;
+// Volume::hit (lib/volume.rs:34-73) after its two boundary hits t1, t2 (volume.rs:35-36).  Draws one random number per
+// call -- once the clipped interval is known to be non-empty -- exactly where the reference draws it.
+RTR_DEV bool volume_finish(float t1, float t2, float neg_inv_density, float a, float tmax, Rng &rng, float &t) {
     if (t1 < kTMin) t1 = kTMin;
     if (t2 > tmax) t2 = tmax;
     if (t1 >= t2) return false;
@@ -305,7 +302,13 @@ RTR_DEV bool volume_t(V3 c, float r2, float neg_inv_density, const Ray &r, float
     t = t1 + hit_distance / ray_length;
     return true;
 }
-
+// ... over a sphere boundary
+RTR_DEV bool volume_t(V3 c, float r2, float neg_inv_density, const Ray &r, float a, float tmax, Rng &rng, float &t) {
+    float t1, t2;
+    if (!sphere_range(c, r2, r, a, -__builtin_inff(), __builtin_inff(), t1)) return false;
+    if (!sphere_range(c, r2, r, a, t1 + kTMin, __builtin_inff(), t2)) return false;
+    return volume_finish(t1, t2, neg_inv_density, a, tmax, rng, t);
+}
 // mesh.rs:146-184 Moeller-Trumbore with the reference's tests (tmax ignored).
 RTR_DEV bool triangle_t(V3 v0, V3 e1, V3 e2, const Ray &r, float &t, float &u, float &v) {
     V3 h = cross(r.d, e2);
@@ -322,6 +325,97 @@ RTR_DEV bool triangle_t(V3 v0, V3 e1, V3 e2, const Ray &r, float &t, float &u, f
     if (!(tt > kTMin)) return false;
     t = tt; u = uu; v = vv;
     return true;
+}
+
+// --- Volume over a mesh boundary (lib/volume.rs:20 `boundary: Box<dyn Object>`) ----------------------------------------
+// Volume::hit calls boundary.hit twice (volume.rs:35-36), with [-inf, +inf] and with [t1 + tmin, +inf].  For a Mesh that
+// is bvh_root.hit(ray, tmin, tmax) (mesh.rs:124-127): every node's box is tested with the caller's range (AABB::hit,
+// aabb.rs:81-137) and Triangle::hit takes tmin both as its determinant epsilon and as the lower bound on t, ignoring tmax
+// (mesh.rs:166,190,151).  The ranges start below zero, so the walk's `kTMin` forms and its culling do not apply: these are
+// the general forms, and the nested walk below visits every pierced box, as the reference does.
+RTR_DEV bool slab_range(const float *bmin, const float *bmax, const Ray &r, V3 inv, float tmin, float tmax) {
+    float t0 = (bmin[0] - r.o.x) * inv.x, t1 = (bmax[0] - r.o.x) * inv.x;
+    tmin = fmaxf(tmin, inv.x < 0.0f ? t1 : t0);
+    tmax = fminf(tmax, inv.x < 0.0f ? t0 : t1);
+    t0 = (bmin[1] - r.o.y) * inv.y; t1 = (bmax[1] - r.o.y) * inv.y;
+    tmin = fmaxf(tmin, inv.y < 0.0f ? t1 : t0);
+    tmax = fminf(tmax, inv.y < 0.0f ? t0 : t1);
+    t0 = (bmin[2] - r.o.z) * inv.z; t1 = (bmax[2] - r.o.z) * inv.z;
+    tmin = fmaxf(tmin, inv.z < 0.0f ? t1 : t0);
+    tmax = fminf(tmax, inv.z < 0.0f ? t0 : t1);
+    return !(tmax <= tmin);
+}
+RTR_DEV bool triangle_range(V3 v0, V3 e1, V3 e2, const Ray &r, float tmin, float &t) {
+    V3 h = cross(r.d, e2);
+    float a = dot(e1, h);
+    if (a > -tmin && a < tmin) return false;
+    float f = 1.0f / a;
+    V3 s = sub(r.o, v0);
+    float uu = f * dot(s, h);
+    if (uu < 0.0f || uu > 1.0f) return false;
+    V3 q = cross(s, e1);
+    float vv = f * dot(r.d, q);
+    if (vv < 0.0f || uu + vv > 1.0f) return false;
+    float tt = f * dot(e2, q);
+    if (!(tt > tmin)) return false;
+    t = tt;
+    return true;
+}
+// Mesh::hit(ray, tmin, tmax) over the flattened subtree `root` (its own box in bmin / bmax).  The lane's traversal stack is
+// used above `sp0` (the outer walk's entries stay untouched); refs only -- nothing is culled, so no entry distances.
+RTR_DEV bool mesh_range_hit(const DevNode *nodes, const DevLeafHot *leaf_hot, uint32_t root, V3 bmin_v, V3 bmax_v, const Ray &r, V3 inv,
+                            float tmin, float tmax, uint32_t *stk_ref, uint32_t sp0, uint32_t lane, float &t_out) {
+    const float bmin[3] = {bmin_v.x, bmin_v.y, bmin_v.z}, bmax[3] = {bmax_v.x, bmax_v.y, bmax_v.z};
+    if (root == REF_NONE) return false;
+    if ((root & (REF_LEAF | REF_PAIR)) != REF_LEAF && !slab_range(bmin, bmax, r, inv, tmin, tmax)) return false;
+    bool found = false;
+    float bt = 0.0f;
+    uint32_t bl = 0u;
+    uint32_t sp = sp0, cur = root;
+    for (;;) {
+        bool pop = false;
+        if (cur & REF_LEAF) {
+            const uint32_t L = cur & REF_INDEX, n = (cur & REF_PAIR) ? 2u : 1u;
+            for (uint32_t k = 0; k < n; k++) {
+                const float4 *hot = reinterpret_cast<const float4 *>(leaf_hot + (L + k));
+                const float4 q0 = hot[0], q1 = hot[1], q2 = hot[2];
+                float t;
+                // merge_optionals (bvh.rs:181-186): the smaller t wins, the later leaf in depth-first order wins exact ties
+                if (triangle_range(mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y), mk(q1.z, q1.w, q2.x), r, tmin, t) &&
+                    (!found || t < bt || (t == bt && L + k > bl))) {
+                    found = true; bt = t; bl = L + k;
+                }
+            }
+            pop = true;
+        } else {
+            const float4 *nq = reinterpret_cast<const float4 *>(nodes + cur);
+            const float4 q0 = nq[0], q1 = nq[1], q2 = nq[2], q3 = nq[3];
+            const float lmin[3] = {q0.x, q0.y, q0.z}, lmax[3] = {q0.w, q1.x, q1.y};
+            const float rmin[3] = {q1.z, q1.w, q2.x}, rmax[3] = {q2.y, q2.z, q2.w};
+            const uint32_t l = __float_as_uint(q3.x), rr = __float_as_uint(q3.y);
+            bool hl = l != REF_NONE, hr = rr != REF_NONE;
+            if (hl && (l & (REF_LEAF | REF_PAIR)) != REF_LEAF) hl = slab_range(lmin, lmax, r, inv, tmin, tmax);
+            if (hr && (rr & (REF_LEAF | REF_PAIR)) != REF_LEAF) hr = slab_range(rmin, rmax, r, inv, tmin, tmax);
+            if (hl && hr) {
+                stk_ref[sp * 64 + lane] = rr;
+                sp++;
+                cur = l;
+            } else if (hl) {
+                cur = l;
+            } else if (hr) {
+                cur = rr;
+            } else {
+                pop = true;
+            }
+        }
+        if (pop) {
+            if (sp == sp0) break;
+            sp--;
+            cur = stk_ref[sp * 64 + lane];
+        }
+    }
+    t_out = bt;
+    return found;
 }
 
 // hipcc sinks the individual 16-B loads of a node / leaf record into the branches that consume them, which turns
@@ -376,8 +470,26 @@ RTR_DEV bool accept_tree(const Best &b, float t, uint32_t leaf) {
     return b.leaf == REF_NONE || t < b.t || (t == b.t && (leaf & REF_INDEX) > (b.leaf & REF_INDEX));
 }
 
-template <bool VOL>
-RTR_DEV void test_leaf(const RenderParams &p, uint32_t ref, const Ray &r, float a, Best &best, Rng &rng) {
+// Volume::hit for the Volume leaf record q0..q2 (rtr_device.h): sphere boundary, or a mesh boundary walked on the lane's
+// stack above `sp`.
+template <uint32_t VOL>
+RTR_DEV bool volume_leaf_t(const RenderParams &p, const float4 &q0, const float4 &q1, const float4 &q2, const Ray &r, V3 inv, float a,
+                           float tmax, Rng &rng, uint32_t *stk_ref, uint32_t sp, uint32_t lane, float &t) {
+    // VOL == 1: every Volume of the scene has a sphere boundary, and the nested mesh walk is not compiled in (it costs the
+    // launch-bounded tree kernels their register budget); VOL == 2: the leaf record says which
+    if (VOL < 2u || __float_as_uint(q1.z) == 0u) return volume_t(mk(q0.x, q0.y, q0.z), q1.x, q1.y, r, a, tmax, rng, t);
+    const V3 bmin = mk(q0.x, q0.y, q0.z), bmax = mk(q2.y, q2.z, q2.w);
+    const uint32_t root = __float_as_uint(q1.w);
+    float t1, t2;
+    if (!mesh_range_hit(p.nodes, p.leaf_hot, root, bmin, bmax, r, inv, -__builtin_inff(), __builtin_inff(), stk_ref, sp, lane, t1)) return false;
+    if (!mesh_range_hit(p.nodes, p.leaf_hot, root, bmin, bmax, r, inv, t1 + kTMin, __builtin_inff(), stk_ref, sp, lane, t2)) return false;
+    return volume_finish(t1, t2, q1.y, a, tmax, rng, t);
+}
+
+template <uint32_t VOL>
+RTR_DEV void test_leaf(const RenderParams &p, uint32_t ref, const Ray &r, V3 inv, float a, Best &best, Rng &rng, uint32_t *stk_ref,
+                       uint32_t sp, uint32_t lane) {
+    (void)inv; (void)stk_ref; (void)sp; (void)lane;
     const float4 *hot = reinterpret_cast<const float4 *>(p.leaf_hot + (ref & REF_INDEX));
     float4 q0 = hot[0], q1 = hot[1], q2 = hot[2];
 #ifndef RTR_X_NO_GATHER_FENCE
@@ -393,7 +505,7 @@ RTR_DEV void test_leaf(const RenderParams &p, uint32_t ref, const Ray &r, float 
     } else if (VOL && (ref & REF_VOL)) {
         float t;
         // Volume::hit(ray, tmin, +inf) as called from the tree (bvh.rs:156)
-        if (volume_t(mk(q0.x, q0.y, q0.z), q1.x, q1.y, r, a, __builtin_inff(), rng, t) && accept_tree(best, t, ref)) {
+        if (volume_leaf_t<VOL>(p, q0, q1, q2, r, inv, a, __builtin_inff(), rng, stk_ref, sp, lane, t) && accept_tree(best, t, ref)) {
             best_take(best, t, best.u, best.v, ref);
         }
     } else {
@@ -432,7 +544,7 @@ RTR_DEV void test_leaf(const RenderParams &p, uint32_t ref, const Ray &r, float 
         if (cur & REF_LEAF) {                                                                                            \
             RTR_LS1(4) RTR_LS(3, true)                                                                                   \
             /* a REF_PAIR ref stands for Split(leaf L, leaf L+1), its box already tested where the ref was read */       \
-            test_leaf<VOL>(p, cur & ~REF_PAIR, RAY, a, best, rng);                                                       \
+            test_leaf<VOL>(p, cur & ~REF_PAIR, RAY, inv, a, best, rng, stk_ref, sp, lane);                               \
             pop_ = !(cur & REF_PAIR);                                                                                    \
             cur = (cur & ~REF_PAIR) + 1u;                                                                                \
         } else {                                                                                                         \
@@ -508,7 +620,7 @@ RTR_DEV void test_leaf(const RenderParams &p, uint32_t ref, const Ray &r, float 
 
 // BvhNode::hit over the tree rooted at `root`, whose own box has already been tested by the caller: the wave-synchronous
 // form (the wave returns when its slowest lane has finished).
-template <bool VOL, bool MESH>
+template <uint32_t VOL, bool MESH>
 RTR_DEV void traverse(const RenderParams &p, uint32_t root, const Ray &r, V3 inv, float a, float tmax_box,
                       Best &best, uint32_t *stk_ref, StackT *stk_t, uint32_t lane, Rng &rng) {
     uint32_t sp = 0;
@@ -530,7 +642,7 @@ RTR_DEV void face_forward(Hit &h, const Ray &r, V3 outward) {
 }
 
 // Build the HitRecord of the winning leaf (objects.rs:45-48 | mesh.rs:185-193).
-template <bool VOL>
+template <uint32_t VOL>
 RTR_DEV void finish_leaf(const RenderParams &p, const Best &best, const Ray &r, Hit &h) {
     uint32_t L = best.leaf & REF_INDEX;
     const float4 *cold = reinterpret_cast<const float4 *>(p.leaf_cold + L);
@@ -567,7 +679,7 @@ struct SphereRegs {
 };
 
 // world.hit (render.rs:38).  Returns false on miss.
-template <uint32_t WORLD, uint32_t NS, bool VOL, bool MESH>
+template <uint32_t WORLD, uint32_t NS, uint32_t VOL, bool MESH>
 RTR_DEV bool world_hit(const RenderParams &p, const Ray &r, Hit &h, uint32_t *stk_ref, StackT *stk_t, uint32_t lane,
                        const SphereRegs<NS> &sr, const uint32_t *lds_spheres, Rng &rng) {
     const float a = dot(r.d, r.d); // objects.rs:25, hoisted per ray
@@ -715,9 +827,9 @@ RTR_DEV bool world_hit(const RenderParams &p, const Ray &r, Hit &h, uint32_t *st
                 if (ref == REF_NONE) continue;
                 if ((ref & REF_LEAF) && !(ref & REF_TRI)) {
                     const float4 *hot = reinterpret_cast<const float4 *>(p.leaf_hot + (ref & REF_INDEX));
-                    float4 q0 = hot[0], q1 = hot[1];
+                    float4 q0 = hot[0], q1 = hot[1], q2 = hot[2];
                     float t;
-                    const bool got = (VOL && (ref & REF_VOL)) ? volume_t(mk(q0.x, q0.y, q0.z), q1.x, q1.y, r, a, closest, rng, t)
+                    const bool got = (VOL && (ref & REF_VOL)) ? volume_leaf_t<VOL>(p, q0, q1, q2, r, inv, a, closest, rng, stk_ref, 0u, lane, t)
                                                      : sphere_t(mk(q0.x, q0.y, q0.z), q1.x, r, a, closest, t);
                     if (got) {
                         closest = t; best_take(best, t, 0.0f, 0.0f, ref);
@@ -1089,7 +1201,7 @@ RTR_DEV void chunk_publish(const RenderParams &p, uint32_t tidx, uint32_t chunk,
 #ifndef RTR_X_WAVES_PER_EU
 #define RTR_X_WAVES_PER_EU 1
 #endif
-template <uint32_t WORLD, uint32_t NS, bool VOL, bool MESH>
+template <uint32_t WORLD, uint32_t NS, uint32_t VOL, bool MESH>
 // 96 scalar registers: a wave's SGPRs come in 16-register granules out of 800 per SIMD, so the 105 the compiler would
 // take (sphere constants + camera + parameters) admit 7 waves per SIMD and 96 admit 8 -- the vector registers (62)
 // already allow 8.  Measured +2.4 % on the headline kernel, neutral on the tree kernels.
@@ -1336,7 +1448,7 @@ constexpr uint32_t kWalkUnroll = RTR_X_WALK_UNROLL;
 #ifndef RTR_X_BVH_WAVES
 #define RTR_X_BVH_WAVES 7 // 72 VGPRs without spills (the compiler takes 75 unasked): 7 waves per SIMD, +0 ... +5 %
 #endif
-template <bool VOL, bool MESH>
+template <uint32_t VOL, bool MESH>
 __attribute__((amdgpu_num_sgpr(RTR_X_BVH_SGPRS)))
 __global__ __launch_bounds__(64, RTR_X_BVH_WAVES) void k_render_bvh(const RenderParams p) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
@@ -1486,7 +1598,7 @@ __global__ __launch_bounds__(64, RTR_X_BVH_WAVES) void k_render_bvh(const Render
 // a pixel's samples in index order afterwards (the same additions as calculate_pixel's loop).  No lane waits for its
 // tile's slowest pixel, and sample ranges need no hand-over between workgroups.
 // 6 waves per SIMD and 128 SGPRs: 80 VGPRs without the spills the 7-wave budget forces on this kernel (+4 ... 5 %)
-template <bool VOL, bool MESH>
+template <uint32_t VOL, bool MESH>
 __attribute__((amdgpu_num_sgpr(128)))
 __global__ __launch_bounds__(64, 6) void k_render_bvh_sp(const RenderParams p) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
@@ -1715,7 +1827,7 @@ __global__ __launch_bounds__(64) void k_wf_generate(const RenderParams p) {
 #ifndef RTR_X_WF_WAVES
 #define RTR_X_WF_WAVES 6
 #endif
-template <bool VOL, bool MESH>
+template <uint32_t VOL, bool MESH>
 __global__ __launch_bounds__(64, RTR_X_WF_WAVES) void k_wf_intersect(const RenderParams p) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const uint32_t lane = threadIdx.x;
@@ -1799,7 +1911,7 @@ __global__ __launch_bounds__(64, RTR_X_WF_WAVES) void k_wf_intersect(const Rende
 
 // The rest of trace_ray (render.rs:39-58) for every path waiting at depth p.wf_depth, full waves of them at a time.
 // LDS: [ring][materials: lds_mats x 8]
-template <bool VOL>
+template <uint32_t VOL>
 __global__ __launch_bounds__(64) void k_wf_shade(const RenderParams p) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const uint32_t lane = threadIdx.x;
@@ -1956,90 +2068,87 @@ hipError_t launch_selftest_sqrt(unsigned long long *d_mismatches, hipStream_t st
 }
 
 // --- launchers (called from rtr_api.cpp) -----------------------------------------------------------------
-template <uint32_t NS>
-static void launch_spheres(const RenderParams &p, uint32_t grid, uint32_t lds_bytes, hipStream_t stream) {
-    hipLaunchKernelGGL((k_render<WORLD_LINEAR_SPHERES, NS, false, false>), dim3(grid), dim3(64), lds_bytes, stream, p);
+// One table of kernel entry points; launching, the occupancy queries and the attribute queries all go through it.
+// Tree kernels are instantiated per Volume level (0: no Volume objects; 1: sphere-bounded ones -- the reference's visit
+// set and order, the random draw inside world.hit; 2: mesh-bounded ones too -- adds the nested mesh walk) and per
+// "scene has triangles" (unconditional slab tests, see RTR_WALK_TRIP).
+#define RTR_FN(...) reinterpret_cast<const void *>(&__VA_ARGS__)
+#define RTR_TREE_TABLE(KERNEL)                                                                                       \
+    {{RTR_FN(KERNEL<0u, false>), RTR_FN(KERNEL<0u, true>)}, {RTR_FN(KERNEL<1u, false>), RTR_FN(KERNEL<1u, true>)},  \
+     {RTR_FN(KERNEL<2u, false>), RTR_FN(KERNEL<2u, true>)}}
+static uint32_t vol_level(const RenderParams &p) { return p.has_volumes > 2u ? 2u : p.has_volumes; }
+
+static const void *render_kernel(const RenderParams &p) {
+    const uint32_t v = vol_level(p), m = p.has_meshes ? 1u : 0u;
+    if (p.world == WORLD_BVH && p.sample_parallel) {
+        static const void *const t[3][2] = RTR_TREE_TABLE(k_render_bvh_sp);
+        return t[v][m];
+    }
+    if (p.world == WORLD_BVH && p.resumable_walk) {
+        static const void *const t[3][2] = RTR_TREE_TABLE(k_render_bvh);
+        return t[v][m];
+    }
+    if (p.world == WORLD_BVH) {
+        static const void *const t[3][2] = {
+            {RTR_FN(k_render<WORLD_BVH, 0, 0u, false>), RTR_FN(k_render<WORLD_BVH, 0, 0u, true>)},
+            {RTR_FN(k_render<WORLD_BVH, 0, 1u, false>), RTR_FN(k_render<WORLD_BVH, 0, 1u, true>)},
+            {RTR_FN(k_render<WORLD_BVH, 0, 2u, false>), RTR_FN(k_render<WORLD_BVH, 0, 2u, true>)}};
+        return t[v][m];
+    }
+    if (p.world == WORLD_LINEAR_GENERIC) {
+        static const void *const t[3] = {RTR_FN(k_render<WORLD_LINEAR_GENERIC, 0, 0u, true>), RTR_FN(k_render<WORLD_LINEAR_GENERIC, 0, 1u, true>),
+                                         RTR_FN(k_render<WORLD_LINEAR_GENERIC, 0, 2u, true>)};
+        return t[v];
+    }
+    static const void *const t[9] = { // number of spheres held in scalar registers (0 = generic loop)
+        RTR_FN(k_render<WORLD_LINEAR_SPHERES, 0, 0u, false>), RTR_FN(k_render<WORLD_LINEAR_SPHERES, 1, 0u, false>),
+        RTR_FN(k_render<WORLD_LINEAR_SPHERES, 2, 0u, false>), RTR_FN(k_render<WORLD_LINEAR_SPHERES, 3, 0u, false>),
+        RTR_FN(k_render<WORLD_LINEAR_SPHERES, 4, 0u, false>), RTR_FN(k_render<WORLD_LINEAR_SPHERES, 5, 0u, false>),
+        RTR_FN(k_render<WORLD_LINEAR_SPHERES, 6, 0u, false>), RTR_FN(k_render<WORLD_LINEAR_SPHERES, 7, 0u, false>),
+        RTR_FN(k_render<WORLD_LINEAR_SPHERES, 8, 0u, false>)};
+    return t[p.sphere_regs <= 8u ? p.sphere_regs : 0u];
+}
+static const void *wf_intersect_kernel(const RenderParams &p) {
+    static const void *const t[3][2] = RTR_TREE_TABLE(k_wf_intersect);
+    return t[vol_level(p)][p.has_meshes ? 1u : 0u];
+}
+static const void *wf_shade_kernel(const RenderParams &p) {
+    static const void *const t[3] = {RTR_FN(k_wf_shade<0u>), RTR_FN(k_wf_shade<1u>), RTR_FN(k_wf_shade<2u>)};
+    return t[vol_level(p)];
+}
+static hipError_t launch_params_kernel(const void *fn, const RenderParams &p, dim3 grid, uint32_t lds_bytes, hipStream_t stream) {
+    RenderParams copy = p;
+    void *args[] = {&copy};
+    return hipLaunchKernel(fn, grid, dim3(64), args, lds_bytes, stream);
 }
 
 hipError_t launch_render(const RenderParams &p, uint32_t grid, uint32_t lds_bytes, hipStream_t stream) {
-    switch (p.world) {
-    case WORLD_LINEAR_SPHERES:
-        switch (p.sphere_regs) { // number of spheres held in scalar registers (0 = generic loop)
-        case 1: launch_spheres<1>(p, grid, lds_bytes, stream); break;
-        case 2: launch_spheres<2>(p, grid, lds_bytes, stream); break;
-        case 3: launch_spheres<3>(p, grid, lds_bytes, stream); break;
-        case 4: launch_spheres<4>(p, grid, lds_bytes, stream); break;
-        case 5: launch_spheres<5>(p, grid, lds_bytes, stream); break;
-        case 6: launch_spheres<6>(p, grid, lds_bytes, stream); break;
-        case 7: launch_spheres<7>(p, grid, lds_bytes, stream); break;
-        case 8: launch_spheres<8>(p, grid, lds_bytes, stream); break;
-        default: launch_spheres<0>(p, grid, lds_bytes, stream); break;
-        }
-        break;
-    case WORLD_BVH: // Volume leaves need the reference's visit set and order: a separate instantiation pays for it
-        // ... and scenes with meshes get the traversal with unconditional slab tests (see `traverse`)
-        if (p.sample_parallel) {
-            if (p.has_volumes && p.has_meshes) hipLaunchKernelGGL((k_render_bvh_sp<true, true>), dim3(grid), dim3(64), lds_bytes, stream, p);
-            else if (p.has_volumes) hipLaunchKernelGGL((k_render_bvh_sp<true, false>), dim3(grid), dim3(64), lds_bytes, stream, p);
-            else if (p.has_meshes) hipLaunchKernelGGL((k_render_bvh_sp<false, true>), dim3(grid), dim3(64), lds_bytes, stream, p);
-            else hipLaunchKernelGGL((k_render_bvh_sp<false, false>), dim3(grid), dim3(64), lds_bytes, stream, p);
-            break;
-        }
-        if (p.resumable_walk) {
-            if (p.has_volumes && p.has_meshes) hipLaunchKernelGGL((k_render_bvh<true, true>), dim3(grid), dim3(64), lds_bytes, stream, p);
-            else if (p.has_volumes) hipLaunchKernelGGL((k_render_bvh<true, false>), dim3(grid), dim3(64), lds_bytes, stream, p);
-            else if (p.has_meshes) hipLaunchKernelGGL((k_render_bvh<false, true>), dim3(grid), dim3(64), lds_bytes, stream, p);
-            else hipLaunchKernelGGL((k_render_bvh<false, false>), dim3(grid), dim3(64), lds_bytes, stream, p);
-            break;
-        }
-        if (p.has_volumes && p.has_meshes) hipLaunchKernelGGL((k_render<WORLD_BVH, 0, true, true>), dim3(grid), dim3(64), lds_bytes, stream, p);
-        else if (p.has_volumes) hipLaunchKernelGGL((k_render<WORLD_BVH, 0, true, false>), dim3(grid), dim3(64), lds_bytes, stream, p);
-        else if (p.has_meshes) hipLaunchKernelGGL((k_render<WORLD_BVH, 0, false, true>), dim3(grid), dim3(64), lds_bytes, stream, p);
-        else hipLaunchKernelGGL((k_render<WORLD_BVH, 0, false, false>), dim3(grid), dim3(64), lds_bytes, stream, p);
-        break;
-    default:
-        if (p.has_volumes) hipLaunchKernelGGL((k_render<WORLD_LINEAR_GENERIC, 0, true, true>), dim3(grid), dim3(64), lds_bytes, stream, p);
-        else hipLaunchKernelGGL((k_render<WORLD_LINEAR_GENERIC, 0, false, true>), dim3(grid), dim3(64), lds_bytes, stream, p);
-        break;
-    }
-    return hipGetLastError();
+    return launch_params_kernel(render_kernel(p), p, dim3(grid), lds_bytes, stream);
 }
 
 hipError_t launch_wf_generate(const RenderParams &p, uint32_t batch_samples, hipStream_t stream) {
     hipLaunchKernelGGL(k_wf_generate, dim3(p.tiles_total, batch_samples), dim3(64), 0, stream, p);
     return hipGetLastError();
 }
-static const void *wf_intersect_kernel(const RenderParams &p) {
-    return p.has_volumes ? (p.has_meshes ? reinterpret_cast<const void *>(k_wf_intersect<true, true>) : reinterpret_cast<const void *>(k_wf_intersect<true, false>))
-                         : (p.has_meshes ? reinterpret_cast<const void *>(k_wf_intersect<false, true>) : reinterpret_cast<const void *>(k_wf_intersect<false, false>));
-}
 uint32_t wf_intersect_lds_bytes(const RenderParams &p) { return p.stack_cap * 64u * (4u + (uint32_t)sizeof(StackT)) + kWfRing * 4u; }
 uint32_t stack_entry_bytes() { return 4u + (uint32_t)sizeof(StackT); }
 uint32_t coop_ball_lds_bytes() { return kCoopWords * 4u; }
 uint32_t wf_shade_lds_bytes(const RenderParams &p) { return (kWfRing + p.lds_materials * 8u) * 4u; }
-// workgroups (one wave each) of k_wf_intersect / k_wf_shade the device keeps resident
-uint32_t wf_resident_waves(const RenderParams &p, bool shade) {
+static uint32_t resident_waves(const void *fn, uint32_t lds_bytes) {
     int per_cu = 0, dev = 0, cus = 0;
-    const void *fn = shade ? (p.has_volumes ? reinterpret_cast<const void *>(k_wf_shade<true>) : reinterpret_cast<const void *>(k_wf_shade<false>))
-                           : wf_intersect_kernel(p);
-    const uint32_t lds = shade ? wf_shade_lds_bytes(p) : wf_intersect_lds_bytes(p);
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 64, lds) != hipSuccess || per_cu <= 0) per_cu = 16;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 64, lds_bytes) != hipSuccess || per_cu <= 0) per_cu = 16;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
     return (uint32_t)per_cu * (uint32_t)cus;
 }
+// workgroups (one wave each) of k_wf_intersect / k_wf_shade the device keeps resident
+uint32_t wf_resident_waves(const RenderParams &p, bool shade) {
+    return shade ? resident_waves(wf_shade_kernel(p), wf_shade_lds_bytes(p)) : resident_waves(wf_intersect_kernel(p), wf_intersect_lds_bytes(p));
+}
 hipError_t launch_wf_intersect(const RenderParams &p, uint32_t grid, hipStream_t stream) {
-    const uint32_t lds = wf_intersect_lds_bytes(p);
-    if (p.has_volumes && p.has_meshes) hipLaunchKernelGGL((k_wf_intersect<true, true>), dim3(grid), dim3(64), lds, stream, p);
-    else if (p.has_volumes) hipLaunchKernelGGL((k_wf_intersect<true, false>), dim3(grid), dim3(64), lds, stream, p);
-    else if (p.has_meshes) hipLaunchKernelGGL((k_wf_intersect<false, true>), dim3(grid), dim3(64), lds, stream, p);
-    else hipLaunchKernelGGL((k_wf_intersect<false, false>), dim3(grid), dim3(64), lds, stream, p);
-    return hipGetLastError();
+    return launch_params_kernel(wf_intersect_kernel(p), p, dim3(grid), wf_intersect_lds_bytes(p), stream);
 }
 hipError_t launch_wf_shade(const RenderParams &p, uint32_t grid, hipStream_t stream) {
-    const uint32_t lds = wf_shade_lds_bytes(p);
-    if (p.has_volumes) hipLaunchKernelGGL((k_wf_shade<true>), dim3(grid), dim3(64), lds, stream, p);
-    else hipLaunchKernelGGL((k_wf_shade<false>), dim3(grid), dim3(64), lds, stream, p);
-    return hipGetLastError();
+    return launch_params_kernel(wf_shade_kernel(p), p, dim3(grid), wf_shade_lds_bytes(p), stream);
 }
 hipError_t wf_intersect_attributes(const RenderParams &p, int *vgprs) {
     hipFuncAttributes attr;
@@ -2062,15 +2171,8 @@ hipError_t launch_resolve(const float *sum_rgba, uint32_t spp, uint32_t n_pixels
     return hipGetLastError();
 }
 
-static const void *render_kernel(const RenderParams &p);
-
 // 64-thread workgroups of the kernel launch_render would take that the current device keeps resident
-uint32_t render_resident_waves(const RenderParams &p, uint32_t lds_bytes) {
-    int per_cu = 0, dev = 0, cus = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, render_kernel(p), 64, lds_bytes) != hipSuccess || per_cu <= 0) per_cu = 16;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-    return (uint32_t)per_cu * (uint32_t)cus;
-}
+uint32_t render_resident_waves(const RenderParams &p, uint32_t lds_bytes) { return resident_waves(render_kernel(p), lds_bytes); }
 
 hipError_t render_kernel_attributes(const RenderParams &p, int *vgprs, int *static_lds) {
     hipFuncAttributes attr;
@@ -2091,38 +2193,6 @@ const char *render_kernel_name(const RenderParams &p) {
     if (p.world == WORLD_LINEAR_GENERIC) return "rtr::k_render<WORLD_LINEAR_GENERIC> (linear world with meshes)";
     return p.sphere_regs ? "rtr::k_render<WORLD_LINEAR_SPHERES, NS> (linear world, spheres in scalar registers)"
                          : "rtr::k_render<WORLD_LINEAR_SPHERES, 0> (linear world, generic sphere loop)";
-}
-
-static const void *render_kernel(const RenderParams &p) {
-    const void *fn;
-    if (p.world == WORLD_BVH && p.sample_parallel)
-        fn = p.has_volumes ? (p.has_meshes ? reinterpret_cast<const void *>(k_render_bvh_sp<true, true>) : reinterpret_cast<const void *>(k_render_bvh_sp<true, false>))
-                           : (p.has_meshes ? reinterpret_cast<const void *>(k_render_bvh_sp<false, true>) : reinterpret_cast<const void *>(k_render_bvh_sp<false, false>));
-    else if (p.world == WORLD_BVH && p.resumable_walk)
-        fn = p.has_volumes ? (p.has_meshes ? reinterpret_cast<const void *>(k_render_bvh<true, true>) : reinterpret_cast<const void *>(k_render_bvh<true, false>))
-                           : (p.has_meshes ? reinterpret_cast<const void *>(k_render_bvh<false, true>) : reinterpret_cast<const void *>(k_render_bvh<false, false>));
-    else if (p.world == WORLD_BVH)
-        fn = p.has_volumes ? (p.has_meshes ? reinterpret_cast<const void *>(k_render<WORLD_BVH, 0, true, true>)
-                                           : reinterpret_cast<const void *>(k_render<WORLD_BVH, 0, true, false>))
-                           : (p.has_meshes ? reinterpret_cast<const void *>(k_render<WORLD_BVH, 0, false, true>)
-                                           : reinterpret_cast<const void *>(k_render<WORLD_BVH, 0, false, false>));
-    else if (p.world == WORLD_LINEAR_GENERIC)
-        fn = p.has_volumes ? reinterpret_cast<const void *>(k_render<WORLD_LINEAR_GENERIC, 0, true, true>)
-                           : reinterpret_cast<const void *>(k_render<WORLD_LINEAR_GENERIC, 0, false, true>);
-    else {
-        switch (p.sphere_regs) {
-        case 1: fn = reinterpret_cast<const void *>(k_render<WORLD_LINEAR_SPHERES, 1, false, false>); break;
-        case 2: fn = reinterpret_cast<const void *>(k_render<WORLD_LINEAR_SPHERES, 2, false, false>); break;
-        case 3: fn = reinterpret_cast<const void *>(k_render<WORLD_LINEAR_SPHERES, 3, false, false>); break;
-        case 4: fn = reinterpret_cast<const void *>(k_render<WORLD_LINEAR_SPHERES, 4, false, false>); break;
-        case 5: fn = reinterpret_cast<const void *>(k_render<WORLD_LINEAR_SPHERES, 5, false, false>); break;
-        case 6: fn = reinterpret_cast<const void *>(k_render<WORLD_LINEAR_SPHERES, 6, false, false>); break;
-        case 7: fn = reinterpret_cast<const void *>(k_render<WORLD_LINEAR_SPHERES, 7, false, false>); break;
-        case 8: fn = reinterpret_cast<const void *>(k_render<WORLD_LINEAR_SPHERES, 8, false, false>); break;
-        default: fn = reinterpret_cast<const void *>(k_render<WORLD_LINEAR_SPHERES, 0, false, false>); break;
-        }
-    }
-    return fn;
 }
 
 } // namespace rtr

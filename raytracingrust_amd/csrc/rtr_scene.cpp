@@ -234,6 +234,7 @@ struct Flattener {
     std::vector<Box> &obj_box;         // per object: box of that root when it is a Split
     std::vector<uint32_t> &obj_height; // per object: Split nodes on its longest root-to-leaf path
     const std::vector<uint32_t> &obj_leaf_base; // per object: first leaf slot = its rank block in the REFERENCE depth-first order
+    const std::vector<uint32_t> &vol_leaf_base; // per volume: first leaf slot of its boundary mesh's triangles (mesh boundaries)
     bool leaf_pairs = true;
     std::vector<uint32_t> obj_pushes; // per object: node records on its longest root-to-leaf path
 
@@ -246,20 +247,38 @@ struct Flattener {
         uint32_t pushes = 0;     // node records on the longest path: what the walk can push (a leaf pair has no record)
     };
 
-    // Volume (lib/volume.rs:19-32) over a sphere boundary: hot = boundary centre, radius, radius^2, -1/density
-    Emitted emit_volume(uint32_t object, const rtr_volume &v) {
+    // Volume (lib/volume.rs:19-32).  Sphere boundary: hot = centre, radius, radius^2, -1/density, kind 0.
+    // Mesh boundary: hot = the mesh's root box (f[0..2] min, f[9..11] max), -1/density, kind 1, the root ref of the mesh's
+    // subtree (always the reference's tree: Volume::hit walks it with ranges that start below zero, where only the
+    // reference's unculled visit order is defined); the triangles' leaf records sit behind the scene tree's leaves.
+    Emitted emit_volume(uint32_t object, uint32_t vi, const rtr_volume &v) {
         uint32_t L = obj_leaf_base[object];
         DevLeafHot hot{};
-        const rtr_sphere &s = v.boundary;
-        hot.f[0] = s.center[0]; hot.f[1] = s.center[1]; hot.f[2] = s.center[2]; hot.f[3] = s.radius;
-        hot.f[4] = s.radius * s.radius;
-        hot.f[5] = v.neg_inv_density;
         DevLeafCold cold{};
-        cold.material = s.material; cold.object = object; cold.handle = 0; // Object::material = boundary.material(), volume.rs:98-100
+        uint32_t pushes = 0;
+        if (v.boundary_kind == RTR_OBJ_MESH) {
+            const MeshBuild &mb = meshes[v.boundary_mesh];
+            Emitted e = emit_mesh_node(object, mb, mb.tree, mb.tree.root, vol_leaf_base[vi]);
+            hot.f[0] = e.box.mn[0]; hot.f[1] = e.box.mn[1]; hot.f[2] = e.box.mn[2];
+            hot.f[9] = e.box.mx[0]; hot.f[10] = e.box.mx[1]; hot.f[11] = e.box.mx[2];
+            const uint32_t kind = 1u;
+            std::memcpy(&hot.f[6], &kind, 4);
+            std::memcpy(&hot.f[7], &e.ref, 4);
+            cold.material = desc.meshes[v.boundary_mesh].material;
+            pushes = e.pushes + 1u; // the nested walk continues on the lane's stack, above the outer walk's entries
+            out.has_mesh_volumes = true;
+        } else {
+            const rtr_sphere &s = v.boundary;
+            hot.f[0] = s.center[0]; hot.f[1] = s.center[1]; hot.f[2] = s.center[2]; hot.f[3] = s.radius;
+            hot.f[4] = s.radius * s.radius;
+            cold.material = s.material;
+        }
+        hot.f[5] = v.neg_inv_density;
+        cold.object = object; cold.handle = 0; // Object::material = boundary.material(), volume.rs:98-100
         out.leaf_hot[L] = hot;
         out.leaf_cold[L] = cold;
         out.has_volumes = true;
-        return {REF_LEAF | REF_VOL | L, Box{}, 0, true};
+        return {REF_LEAF | REF_VOL | L, Box{}, 0, true, pushes};
     }
 
     Emitted emit_sphere(uint32_t object, const rtr_sphere &s) {
@@ -308,7 +327,7 @@ struct Flattener {
         if (o.kind == RTR_OBJ_SPHERE) {
             e = emit_sphere(object, desc.spheres[o.index]);
         } else if (o.kind == RTR_OBJ_VOLUME) {
-            e = emit_volume(object, desc.volumes[o.index]);
+            e = emit_volume(object, o.index, desc.volumes[o.index]);
         } else {
             const MeshBuild &mb = meshes[o.index];
             const uint32_t leaf_base = obj_leaf_base[object];
@@ -496,11 +515,20 @@ int build_flat_scene(const rtr_scene_desc &desc, FlatScene &out, std::string &er
             }
         } else if (o.kind == RTR_OBJ_VOLUME) {
             if (o.index >= desc.n_volumes) { err = "volume index out of bounds"; return RTR_ERR_BAD_INDEX; }
-            const rtr_sphere &s = desc.volumes[o.index].boundary;
-            if (s.material >= desc.n_materials) { err = "volume material out of bounds"; return RTR_ERR_BAD_INDEX; }
-            for (int k = 0; k < 3; k++) { // Bounded for Volume = boundary.bounds(), volume.rs:90-94
-                ob[i].mn[k] = s.center[k] - s.radius;
-                ob[i].mx[k] = s.center[k] + s.radius;
+            const rtr_volume &v = desc.volumes[o.index];
+            if (v.boundary_kind == RTR_OBJ_MESH) {
+                if (v.boundary_mesh >= desc.n_meshes) { err = "volume boundary mesh out of bounds"; return RTR_ERR_BAD_INDEX; }
+                ob[i] = meshes[v.boundary_mesh].bounds; // Bounded for Volume = boundary.bounds(), volume.rs:90-94
+            } else if (v.boundary_kind == RTR_OBJ_SPHERE) {
+                const rtr_sphere &s = v.boundary;
+                if (s.material >= desc.n_materials) { err = "volume material out of bounds"; return RTR_ERR_BAD_INDEX; }
+                for (int k = 0; k < 3; k++) {
+                    ob[i].mn[k] = s.center[k] - s.radius;
+                    ob[i].mx[k] = s.center[k] + s.radius;
+                }
+            } else {
+                err = "a Volume's boundary is a sphere or a mesh";
+                return RTR_ERR_UNSUPPORTED;
             }
             out.spheres_only = false;
         } else if (o.kind == RTR_OBJ_MESH) {
@@ -524,6 +552,7 @@ int build_flat_scene(const rtr_scene_desc &desc, FlatScene &out, std::string &er
     // Leaf slots: every object owns a block of leaf records, the blocks laid out in the reference scene tree's
     // depth-first order, so a leaf's index is its reference rank whichever topology is walked.
     std::vector<uint32_t> obj_leaf_base(desc.n_objects, 0u);
+    std::vector<uint32_t> vol_leaf_base(desc.n_volumes, 0u);
     {
         uint32_t next = 0;
         std::vector<int32_t> todo{scene_tree.root};
@@ -540,6 +569,13 @@ int build_flat_scene(const rtr_scene_desc &desc, FlatScene &out, std::string &er
                 todo.push_back(n.left);
             }
         }
+        // the triangles of meshes that bound a Volume: behind the scene tree's leaves (their ranks order ties inside the
+        // boundary mesh only)
+        for (uint32_t vi = 0; vi < desc.n_volumes; vi++)
+            if (desc.volumes[vi].boundary_kind == RTR_OBJ_MESH && desc.volumes[vi].boundary_mesh < desc.n_meshes) {
+                vol_leaf_base[vi] = next;
+                next += desc.meshes[desc.volumes[vi].boundary_mesh].n_tris;
+            }
         out.leaf_hot.assign(next, DevLeafHot{});
         out.leaf_cold.assign(next, DevLeafCold{});
     }
@@ -567,7 +603,7 @@ int build_flat_scene(const rtr_scene_desc &desc, FlatScene &out, std::string &er
     std::vector<uint32_t> obj_ref(desc.n_objects, REF_NONE);
     std::vector<Box> obj_box(desc.n_objects);
     std::vector<uint32_t> obj_height(desc.n_objects, 0);
-    Flattener fl{desc, meshes, scene_walk, out, obj_ref, obj_box, obj_height, obj_leaf_base};
+    Flattener fl{desc, meshes, scene_walk, out, obj_ref, obj_box, obj_height, obj_leaf_base, vol_leaf_base};
     fl.leaf_pairs = opts.leaf_pairs;
     Flattener::Emitted root = fl.emit_scene_node(scene_walk.root);
     out.root_ref = root.ref;

@@ -34,6 +34,7 @@ struct FlatScene {
     uint32_t mesh_height = 0;   // same, over the mesh subtrees alone (linear world with meshes)
     bool spheres_only = true;
     bool has_volumes = false;   // a Volume leaf exists: traversal must keep the reference's visit set and order
+    bool has_mesh_volumes = false; // ... and one of them is bounded by a mesh (nested mesh walk inside Volume::hit)
     uint32_t n_objects = 0, n_spheres = 0, n_meshes = 0, n_triangles = 0;
 };
 

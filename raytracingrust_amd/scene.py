@@ -162,11 +162,12 @@ class Sphere:
 
 class Volume:
     """lib/volume.rs:19-32: a constant-density medium inside a boundary object (`Volume::new(boundary, density)`
-    stores -1/density).  The GPU path takes a Sphere boundary; its material (normally Isotropic) is the medium's."""
+    stores -1/density).  The boundary is a Sphere or a Mesh (`boundary: Box<dyn Object>`; a Volume inside a Volume is
+    not lowered); its material (normally Isotropic) is the medium's."""
 
-    def __init__(self, boundary: "Sphere", density: float):
-        if not isinstance(boundary, Sphere):
-            raise TypeError("Volume boundaries other than Sphere are outside the GPU path")
+    def __init__(self, boundary: Union["Sphere", "Mesh"], density: float):
+        if not isinstance(boundary, (Sphere, Mesh)):
+            raise TypeError("Volume boundaries are Sphere or Mesh")
         self.boundary = boundary
         self.density = float(f32(density))
 
@@ -417,7 +418,7 @@ class Scene:
             elif t == "Volume":
                 b = o["boundary"]
                 if b.get("type") != "Sphere":
-                    raise ValueError("Volume boundaries other than Sphere are outside the GPU path")
+                    raise ValueError("a Volume over anything but a Sphere cannot be deserialized (Mesh panics in the reference: mesh.rs:51-60)")
                 vol = Volume(Sphere(_xyz(b["center"]), b["radius"], int(b["material"])), 1.0)
                 vol.density = float(f32(-1.0) / f32(o["neg_inv_density"]))
                 vol._neg_inv_density = float(f32(o["neg_inv_density"]))  # keep the stored value bit for bit
@@ -464,6 +465,8 @@ class Scene:
             if isinstance(o, Sphere):
                 objects.append(sphere(o))
             elif isinstance(o, Volume):
+                if not isinstance(o.boundary, Sphere):
+                    raise ValueError("a Volume over a Mesh cannot be serialized (Mesh panics in the reference: mesh.rs:40-49)")
                 objects.append({"type": "Volume", "boundary": sphere(o.boundary), "neg_inv_density": num(o.neg_inv_density)})
             else:
                 raise ValueError("Mesh cannot be serialized (the reference panics: mesh.rs:40-49)")
@@ -562,9 +565,11 @@ class LoweredScene:
     def __init__(self, scene: Scene):
         self._keep = []
         spheres = [o for o in scene.objects if isinstance(o, Sphere)]
-        meshes = [o for o in scene.objects if isinstance(o, Mesh)]
         volumes = [o for o in scene.objects if isinstance(o, Volume)]
-        if len(spheres) + len(meshes) + len(volumes) != len(scene.objects):
+        # meshes[]: the scene's Mesh objects, then the meshes that only bound a Volume (not objects themselves)
+        meshes = [o for o in scene.objects if isinstance(o, Mesh)] + [v.boundary for v in volumes if isinstance(v.boundary, Mesh)]
+        n_obj_meshes = sum(isinstance(o, Mesh) for o in scene.objects)
+        if len(spheres) + n_obj_meshes + len(volumes) != len(scene.objects):
             raise TypeError("Scene.objects may hold Sphere, Mesh and Volume only")
         vol = (_capi.rtr_volume * max(len(volumes), 1))()
         vi = 0
@@ -572,7 +577,16 @@ class LoweredScene:
         objs = (_capi.rtr_object * max(n_obj, 1))()
         sph = (_capi.rtr_sphere * max(len(spheres), 1))()
         msh = (_capi.rtr_mesh * max(len(meshes), 1))()
+        for mi, o in enumerate(meshes):
+            self._keep += [o.positions, o.normals, o.indices]
+            msh[mi].positions = o.positions.ctypes.data_as(C.POINTER(C.c_float))
+            msh[mi].normals = o.normals.ctypes.data_as(C.POINTER(C.c_float))
+            msh[mi].indices = o.indices.ctypes.data_as(C.POINTER(C.c_uint32))
+            msh[mi].n_verts = o.positions.shape[0]
+            msh[mi].n_tris = o.n_tris
+            msh[mi].material = o.material
         si = mi = 0
+        bi = n_obj_meshes  # next boundary-only mesh
         for i, o in enumerate(scene.objects):
             if isinstance(o, Sphere):
                 objs[i].kind, objs[i].index = 0, si
@@ -583,20 +597,19 @@ class LoweredScene:
             elif isinstance(o, Volume):
                 objs[i].kind, objs[i].index = 2, vi
                 b = o.boundary
-                vol[vi].boundary.center = _capi.c_float3(*[float(x) for x in b.center])
-                vol[vi].boundary.radius = b.radius
-                vol[vi].boundary.material = b.material
+                if isinstance(b, Sphere):
+                    vol[vi].boundary.center = _capi.c_float3(*[float(x) for x in b.center])
+                    vol[vi].boundary.radius = b.radius
+                    vol[vi].boundary.material = b.material
+                    vol[vi].boundary_kind = 0
+                else:
+                    vol[vi].boundary.material = b.material
+                    vol[vi].boundary_kind, vol[vi].boundary_mesh = 1, bi
+                    bi += 1
                 vol[vi].neg_inv_density = o.neg_inv_density
                 vi += 1
             else:
                 objs[i].kind, objs[i].index = 1, mi
-                self._keep += [o.positions, o.normals, o.indices]
-                msh[mi].positions = o.positions.ctypes.data_as(C.POINTER(C.c_float))
-                msh[mi].normals = o.normals.ctypes.data_as(C.POINTER(C.c_float))
-                msh[mi].indices = o.indices.ctypes.data_as(C.POINTER(C.c_uint32))
-                msh[mi].n_verts = o.positions.shape[0]
-                msh[mi].n_tris = o.n_tris
-                msh[mi].material = o.material
                 mi += 1
         lm = scene.lowered_materials()
         mats = (_capi.rtr_material * max(len(lm), 1))()

@@ -235,6 +235,48 @@ def test_volume_fog(gpu_renderer, bvh, two):
     assert c["max_u8_delta"] == 0
 
 
+def _mesh_fog_scene(bvh, spp=4, with_sphere_fog=True):
+    """Volume over a MESH boundary (volume.rs:20 `boundary: Box<dyn Object>`): smoke inside cube.obj and inside the monkey,
+    next to solids, a mesh object and (optionally) a sphere-bounded fog -- the two boundary.hit calls of Volume::hit then
+    walk the boundary mesh's own tree with the ranges [-inf, inf] and [t1 + tmin, inf] (mesh.rs:124-127,146-197)."""
+    from raytracingrust_amd.configs import mesh_path
+
+    s = rt.Scene()
+    s.camera = rt.Camera([0.3, 0.6, 3.2], [0.0, 0.0, 0.0], [0.0, 1.0, 0.0], 55.0, 1.5)
+    s.settings.samples_per_pixel = spp
+    s.settings.enable_bvh_tree = bvh
+    s.settings.max_ray_depth = 8
+    s.background = rt.GradientBackground([1.0, 1.0, 1.0], [0.5, 0.7, 1.0])
+    ground = s.add_material(rt.Lambertian([0.5, 0.5, 0.5]))
+    red = s.add_material(rt.Lambertian([0.8, 0.2, 0.2]))
+    smoke = s.add_material(rt.Isotropic([0.15, 0.15, 0.2]))
+    mist = s.add_material(rt.Isotropic([0.9, 0.9, 0.9]))
+    s.add_object(rt.Sphere([0.0, -101.0, 0.0], 100.0, ground))
+    cube = rt.Mesh.from_file(mesh_path("cube.obj"), smoke)
+    cube.positions = (cube.positions * np.float32(0.6) + np.array([-0.9, -0.2, 0.0], dtype=np.float32)).astype(np.float32)
+    s.add_object(rt.Volume(cube, 3.0))
+    s.add_object(rt.Sphere([1.3, -0.5, -0.3], 0.5, red))
+    monkey = rt.Mesh.from_file(mesh_path("monkey.obj"), mist)
+    monkey.positions = (monkey.positions * np.float32(0.8) + np.array([0.5, 0.1, 0.2], dtype=np.float32)).astype(np.float32)
+    s.add_object(rt.Volume(monkey, 6.0))
+    plane = rt.Mesh.from_file(mesh_path("plane.obj"), red)
+    plane.positions = (plane.positions * np.float32(0.5) + np.array([0.0, 1.4, -0.5], dtype=np.float32)).astype(np.float32)
+    s.add_object(plane)
+    if with_sphere_fog:
+        s.add_object(rt.Volume(rt.Sphere([0.0, 0.0, 0.0], 25.0, mist), 0.05))
+    return s
+
+
+@pytest.mark.parametrize("bvh", [True, False])
+@pytest.mark.parametrize("sphere_fog", [False, True])
+def test_volume_over_a_mesh_boundary(gpu_renderer, bvh, sphere_fog):
+    """Bit-exact against the oracle, whose Volume takes any boundary through the reference's own Mesh::hit restatement."""
+    c, st, o_st = run_both(gpu_renderer, _mesh_fog_scene(bvh, with_sphere_fog=sphere_fog), 96, 64, 17)
+    assert st.segments == o_st.segments
+    assert c["mismatched_pixels"] == 0, c
+    assert c["max_u8_delta"] == 0
+
+
 @pytest.mark.parametrize("w,h", [(1, 1), (1, 9), (9, 1), (2, 2), (8, 8), (9, 9)])
 def test_degenerate_target_sizes(gpu_renderer, w, h):
     """render.rs:88-89 divides by (W-1) and (H-1): a 1-pixel-wide target makes u or v inf/NaN.  The reference does
@@ -520,6 +562,7 @@ def _tiny_tree_scene(n):
                                          (lambda: monkey_scene(3, material=rt.Dielectric(1.5)), 128, 72),
                                          (lambda: benchmark_scene(4, enable_bvh_tree=True), 128, 72),
                                          (lambda: _fog_scene(True, two_volumes=True), 96, 64),
+                                         (lambda: _mesh_fog_scene(True, spp=3), 72, 48),
                                          (lambda: _tiny_tree_scene(0), 40, 24), (lambda: _tiny_tree_scene(1), 40, 24),
                                          (lambda: _tiny_tree_scene(2), 40, 24), (lambda: _tiny_tree_scene(3), 40, 24)])
 def test_tree_kernels_agree_bit_for_bit(builder, w, h):

@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), f"librtr_hip.so does not export {name}"
     bound = {n for n, _, _ in _capi.SYMBOLS}
     assert declared == bound, declared ^ bound
-    assert _capi.load().rtr_abi_version() == 3
+    assert _capi.load().rtr_abi_version() == 4
 
 
 def test_struct_layouts_match_the_header():
@@ -31,7 +31,7 @@ def test_struct_layouts_match_the_header():
     assert C.sizeof(_capi.rtr_object) == 8 and C.sizeof(_capi.rtr_camera) == 44
     assert C.sizeof(_capi.rtr_settings) == 24 and C.sizeof(_capi.rtr_mesh) == 40
     assert C.sizeof(_capi.rtr_background) == 48 and C.sizeof(_capi.rtr_scene_desc) == 64 + 48 + 16
-    assert C.sizeof(_capi.rtr_volume) == 24
+    assert C.sizeof(_capi.rtr_volume) == 32  # ABI 4: + boundary_kind, boundary_mesh
 
 
 def test_host_only_context_refuses_to_render():
