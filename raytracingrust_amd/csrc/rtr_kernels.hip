@@ -517,9 +517,10 @@ RTR_DEV void test_leaf(const RenderParams &p, uint32_t ref, const Ray &r, V3 inv
     }
 }
 
-// One trip of BvhNode::hit (bvh.rs:146-172) over the flattened tree for a lane whose walk is in progress: a leaf test
-// (the second leaf of a collapsed pair follows in the next trip, no stack traffic) or a node step (both children's boxes
-// from one 64-byte record), then, when the lane has nowhere to descend, a pop.  The reference visits both children of
+// One trip of BvhNode::hit (bvh.rs:146-172) over the flattened tree for a lane whose walk is in progress: a node step (both
+// children's boxes from one 64-byte record) unless the lane stands at a leaf, then a leaf test if it stands at one now (the
+// second leaf of a collapsed pair follows in the next trip, no stack traffic), then, when the lane has nowhere to descend,
+// a pop.  The reference visits both children of
 // every pierced box with the caller's [tmin, tmax]; here children are visited nearest-entry first and a box is skipped
 // when it is entered beyond the best hit (Best::cull) -- nothing inside it can win or tie.
 // Volume leaves draw a random number on every visit (volume.rs:57), so a subtree that holds one is visited exactly when,
@@ -536,18 +537,18 @@ RTR_DEV void test_leaf(const RenderParams &p, uint32_t ref, const Ray &r, V3 inv
 // triangles of a pair in one 96-byte gather, +13 VGPRs and no faster; an explicit bound test on the push, -1 ... -4 %:
 // one push per node record on the path, sp <= tree height < p.stack_cap by construction of the flattener, checked on the
 // host by tests/cpp/scene_sanity.cpp.)
+#ifndef RTR_X_LEAF_NEXT_TRIP
+#define RTR_LEAF_NOW_ (!pop_ && (cur & REF_LEAF))
+#else // round-1 form, for A/B runs: only lanes that stood at a leaf when the trip began test it
+#define RTR_LEAF_NOW_ leaf0_
+#endif
 #define RTR_WALK_TRIP(RAY, TMAX_BOX, ON_EMPTY)                                                                           \
     {                                                                                                                    \
         RTR_LS1(1) RTR_LS(2, true)                                                                                       \
         bool pop_ = false;                                                                                               \
         /* (cur is never REF_NONE here: the callers test the root, a node step tests both children before descending) */ \
-        if (cur & REF_LEAF) {                                                                                            \
-            RTR_LS1(4) RTR_LS(3, true)                                                                                   \
-            /* a REF_PAIR ref stands for Split(leaf L, leaf L+1), its box already tested where the ref was read */       \
-            test_leaf<VOL>(p, cur & ~REF_PAIR, RAY, inv, a, best, rng, stk_ref, sp, lane);                               \
-            pop_ = !(cur & REF_PAIR);                                                                                    \
-            cur = (cur & ~REF_PAIR) + 1u;                                                                                \
-        } else {                                                                                                         \
+        const bool leaf0_ = (cur & REF_LEAF) != 0u;                                                                      \
+        if (!leaf0_) {                                                                                                   \
             RTR_LS1(6) RTR_LS(5, true)                                                                                   \
             const float4 *nq_ = reinterpret_cast<const float4 *>(p.nodes + cur);                                         \
             float4 q0_ = nq_[0], q1_ = nq_[1], q2_ = nq_[2], q3_ = nq_[3];                                               \
@@ -600,6 +601,16 @@ RTR_DEV void test_leaf(const RenderParams &p, uint32_t ref, const Ray &r, V3 inv
             } else {                                                                                                     \
                 pop_ = true;                                                                                             \
             }                                                                                                            \
+        }                                                                                                                \
+        /* A lane whose node step has just descended into a leaf tests it in the same trip (and so does a lane that stood */ \
+        /* at a leaf when the trip began): a leaf visit costs no trip of its own.  Same operations per lane in the same  */ \
+        /* order; 5-6 % fewer wave trips' worth of time on C1 / C3 / C4 (round 2).                                       */ \
+        if (RTR_LEAF_NOW_) {                                                                                             \
+            RTR_LS1(4) RTR_LS(3, true)                                                                                   \
+            /* a REF_PAIR ref stands for Split(leaf L, leaf L+1), its box already tested where the ref was read */       \
+            test_leaf<VOL>(p, cur & ~REF_PAIR, RAY, inv, a, best, rng, stk_ref, sp, lane);                               \
+            pop_ = !(cur & REF_PAIR);                                                                                    \
+            cur = (cur & ~REF_PAIR) + 1u;                                                                                \
         }                                                                                                                \
         if (pop_) {                                                                                                      \
             RTR_LS1(8) RTR_LS(7, true)                                                                                   \
