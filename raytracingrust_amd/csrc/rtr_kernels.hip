@@ -926,8 +926,16 @@ RTR_DEV V3 background(const RenderParams &p, const Ray &r) {
     float sy = poly_atan2(-d.z, d.x) + kPi;
     float u = sx / kPi;
     float v = sy / (2.0f * kPi);
-    unsigned long long x = sat_usize(v * (float)p.sky_w) % p.sky_w;
-    unsigned long long y = (unsigned long long)p.sky_h - 1ull - sat_usize(u * (float)p.sky_h) % p.sky_h;
+    // `(v * W) as usize % W` (backgrounds.rs:88-89).  v and u lie in [0, 1], so the product is below W except when the
+    // coordinate is exactly 1: the 64-bit remainder -- a software division, ~150 instructions, twice per escaping path --
+    // is taken only then (or for a NaN / out-of-range direction); the value is the same either way.
+    const float fx = v * (float)p.sky_w, fy = u * (float)p.sky_h;
+    uint32_t xi, yi;
+    if (fx >= 0.0f && fx < (float)p.sky_w) xi = (uint32_t)fx; // (uint32_t)fx < W: no remainder to take
+    else xi = (uint32_t)(sat_usize(fx) % p.sky_w);
+    if (fy >= 0.0f && fy < (float)p.sky_h) yi = (uint32_t)fy;
+    else yi = (uint32_t)(sat_usize(fy) % p.sky_h);
+    const unsigned long long x = xi, y = (unsigned long long)p.sky_h - 1ull - yi;
     float4 texel = reinterpret_cast<const float4 *>(p.sky)[x + y * p.sky_w];
     return mk(texel.x, texel.y, texel.z);
 }
