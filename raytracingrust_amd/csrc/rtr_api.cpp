@@ -26,7 +26,7 @@ hipError_t launch_resolve(const float *sum_rgba, uint32_t spp, uint32_t n_pixels
 hipError_t render_kernel_attributes(const RenderParams &p, int *vgprs, int *static_lds);
 uint32_t render_resident_waves(const RenderParams &p, uint32_t lds_bytes);
 const char *render_kernel_name(const RenderParams &p);
-hipError_t launch_sum_samples(const float *samples, uint32_t n_samples, float *acc_io, bool first_batch, bool last_batch, uint32_t spp,
+hipError_t launch_sum_samples(const RenderParams &p, const float *samples, uint32_t n_samples, float *acc_io, bool first_batch, bool last_batch, uint32_t spp,
                               uint32_t n_pixels, float *sum_rgba, uint8_t *rgba8, float *mean_rgb, hipStream_t stream);
 hipError_t launch_selftest_sqrt(unsigned long long *d_mismatches, hipStream_t stream);
 hipError_t launch_debug_fault(unsigned long long *fault, hipStream_t stream);
@@ -396,7 +396,7 @@ int launch_frame(rtr_context *ctx, const rtr_camera *camera, const rtr_settings 
                 p.wf_ray = b.wf_ray; // (for render_kernel_name below)
             }
             if (last) RTR_HIP_TRY(ctx, hipEventRecord(ctx->ev_mid[slot], stream));
-            RTR_HIP_TRY(ctx, rtr::launch_sum_samples(p.samples, b.sample_count, static_cast<float *>(ctx->d_carry), first, last, p.spp,
+            RTR_HIP_TRY(ctx, rtr::launch_sum_samples(p, p.samples, b.sample_count, static_cast<float *>(ctx->d_carry), first, last, p.spp,
                                                      width * height, d_sum_rgba, d_rgba8, d_mean_rgb, stream));
         }
     }

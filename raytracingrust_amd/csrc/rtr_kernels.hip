@@ -137,7 +137,7 @@ RTR_DEV float poly_acos(float x) {
     float a = fabsf(x);
     if (a <= 0.5f) return 1.57079632679489661923f - poly_asin_core(x);
     float z = (1.0f - a) * 0.5f;
-    float r = 2.0f * poly_asin_core(sqrtf(z));
+    float r = 2.0f * poly_asin_core(rt_sqrt(z)); // (rt_sqrt == sqrtf bit for bit: rtr_selftest_sqrt)
     return x > 0.0f ? r : kPi - r;
 }
 RTR_DEV float poly_atan_pos(float x) {
@@ -913,15 +913,9 @@ RTR_DEV V3 material_rgb(const RenderParams &p, const uint32_t *lds_mats, uint32_
     return mk(q.x, q.y, q.z);
 }
 
-// Background::sample (backgrounds.rs)
-RTR_DEV V3 background(const RenderParams &p, const Ray &r) {
-    if (p.bg_kind == 0u) return ld3(p.bg_a); // backgrounds.rs:25-30
-    if (p.bg_kind == 1u) {                   // backgrounds.rs:44-49, ray.rs:19-26
-        float t = 0.5f * (normalize(r.d).y + 1.0f);
-        return add(scale(ld3(p.bg_a), 1.0f - t), scale(ld3(p.bg_b), t));
-    }
-    // backgrounds.rs:84-92, math.rs:24-29: nearest texel of an equirectangular image
-    V3 d = normalize(r.d);
+// SkyMap::sample's texel (backgrounds.rs:84-92, math.rs:24-29): index into the row-major image, row 0 = top
+RTR_DEV unsigned long long sky_texel_index(const RenderParams &p, V3 dir) {
+    V3 d = normalize(dir);
     float sx = poly_acos(-d.y);
     float sy = poly_atan2(-d.z, d.x) + kPi;
     float u = sx / kPi;
@@ -936,7 +930,17 @@ RTR_DEV V3 background(const RenderParams &p, const Ray &r) {
     if (fy >= 0.0f && fy < (float)p.sky_h) yi = (uint32_t)fy;
     else yi = (uint32_t)(sat_usize(fy) % p.sky_h);
     const unsigned long long x = xi, y = (unsigned long long)p.sky_h - 1ull - yi;
-    float4 texel = reinterpret_cast<const float4 *>(p.sky)[x + y * p.sky_w];
+    return x + y * p.sky_w;
+}
+// Background::sample (backgrounds.rs)
+RTR_DEV V3 background(const RenderParams &p, const Ray &r) {
+    if (p.bg_kind == 0u) return ld3(p.bg_a); // backgrounds.rs:25-30
+    if (p.bg_kind == 1u) {                   // backgrounds.rs:44-49, ray.rs:19-26
+        float t = 0.5f * (normalize(r.d).y + 1.0f);
+        return add(scale(ld3(p.bg_a), 1.0f - t), scale(ld3(p.bg_b), t));
+    }
+    // backgrounds.rs:84-92, math.rs:24-29: nearest texel of an equirectangular image
+    const float4 texel = reinterpret_cast<const float4 *>(p.sky)[sky_texel_index(p, r.d)];
     return mk(texel.x, texel.y, texel.z);
 }
 
@@ -957,13 +961,8 @@ struct GlobalChain {
     RTR_DEV uint32_t pop() { n--; return base[(uint64_t)n * stride + path]; }
 };
 
-// attenuation * (attenuation * (... * terminal)) (render.rs:52), then f32::clamp(0, clamp_indirect) with NaN staying
-// NaN (render.rs:95-97): the radiance one finished sample adds to its pixel
-template <class Chain>
-RTR_DEV V3 sample_radiance(const RenderParams &p, const uint32_t *lds_mats, Chain &chain, V3 term) {
-    while (chain.n > 0u) {
-        term = mul(material_rgb(p, lds_mats, chain.pop()), term);
-    }
+// f32::clamp(0, clamp_indirect) per channel with NaN staying NaN (render.rs:95-97)
+RTR_DEV V3 clamp_radiance(const RenderParams &p, V3 term) {
     const float hi = p.clamp_indirect;
     if (term.x < 0.0f) term.x = 0.0f;
     if (term.x > hi) term.x = hi;
@@ -972,6 +971,15 @@ RTR_DEV V3 sample_radiance(const RenderParams &p, const uint32_t *lds_mats, Chai
     if (term.z < 0.0f) term.z = 0.0f;
     if (term.z > hi) term.z = hi;
     return term;
+}
+// attenuation * (attenuation * (... * terminal)) (render.rs:52), then the clamp: the radiance one finished sample adds
+// to its pixel
+template <class Chain>
+RTR_DEV V3 sample_radiance(const RenderParams &p, const uint32_t *lds_mats, Chain &chain, V3 term) {
+    while (chain.n > 0u) {
+        term = mul(material_rgb(p, lds_mats, chain.pop()), term);
+    }
+    return clamp_radiance(p, term);
 }
 
 // --- the rejection sampler, wave-cooperative -------------------------------------------------------------------------
@@ -1061,7 +1069,8 @@ RTR_DEV V3 coop_ball(const CoopBall &cb, bool need, Rng &rng, uint32_t lane, flo
 // with `active` false for the lanes that have no segment to shade (they take part in the sampler's rounds only).
 template <bool COOP = false, class Chain>
 RTR_DEV bool shade_segment(const RenderParams &p, bool was_hit, const Hit &h, Ray &ray, Rng &rng, const uint32_t *lds_mats,
-                           Chain &chain, uint32_t lane, uint32_t &depth, V3 &term, bool active = true, const CoopBall *coop = nullptr) {
+                           Chain &chain, uint32_t lane, uint32_t &depth, V3 &term, bool active = true, const CoopBall *coop = nullptr,
+                           bool *defer_sky = nullptr) {
     (void)lane; (void)coop;
     bool done = false;
     uint32_t kind = 7u, mid = 0u; // 7: no material to scatter from (inactive lane, miss, or a mode that returns at once)
@@ -1070,7 +1079,9 @@ RTR_DEV bool shade_segment(const RenderParams &p, bool was_hit, const Hit &h, Ra
     RTR_LS(17, active && !was_hit)
     if (active) {
         if (!was_hit) {
-            term = background(p, ray);
+            // defer_sky: the caller evaluates SkyMap::sample later, from the direction (k_render_bvh_sp -> k_sum_samples)
+            if (defer_sky && p.bg_kind == 2u) { *defer_sky = true; term = ray.d; }
+            else term = background(p, ray);
             done = true;
         } else if (p.mode == 3u) { // RenderMode::Normal, render.rs:42-45
             V3 n = scale(add(normalize(h.normal), mk(1.0f, 1.0f, 1.0f)), 0.5f);
@@ -1750,10 +1761,29 @@ __global__ __launch_bounds__(64, 6) void k_render_bvh_sp(const RenderParams p) {
             const bool was_hit = best.leaf != REF_NONE;
             if (was_hit) finish_leaf<VOL>(p, best, ray, h);
             V3 term;
-            const bool done = shade_segment(p, was_hit, h, ray, rng, lds_mats, chain, lane, depth, term);
+            bool sky = false;
+            const bool done = shade_segment(p, was_hit, h, ray, rng, lds_mats, chain, lane, depth, term, true, nullptr, &sky);
             if (done) { // the sample's clamped radiance (render.rs:95-97) goes to memory; k_sum_samples adds them in order
-                const V3 rad = sample_radiance(p, lds_mats, chain, term);
-                reinterpret_cast<float4 *>(p.samples)[slot] = make_float4(rad.x, rad.y, rad.z, 0.0f);
+                // A path that escapes to a SkyMap leaves its DIRECTION and its attenuation chain instead (up to 3 material
+                // ids below 256, packed into the fourth word): k_sum_samples, whose lanes are all busy, does the
+                // normalize / acos / atan2 / texel fetch / chain product / clamp -- the same operations on the same values
+                // -- that would run here for the ~20 lanes of a shading round that escape, with an HBM-latency gather in
+                // the middle of a loop of L2 hits.
+                uint32_t packed = 0x80000000u | (chain.n << 24);
+                bool fits = sky && chain.n <= 3u;
+                for (uint32_t j = 0; fits && j < chain.n; j++) {
+                    const uint32_t id = chain.base[j * 64u + lane];
+                    fits = id < 256u;
+                    packed |= id << (8u * j);
+                }
+                if (fits) {
+                    reinterpret_cast<float4 *>(p.samples)[slot] = make_float4(term.x, term.y, term.z, __uint_as_float(packed));
+                    chain.n = 0u;
+                } else {
+                    if (sky) term = background(p, ray);
+                    const V3 rad = sample_radiance(p, lds_mats, chain, term);
+                    reinterpret_cast<float4 *>(p.samples)[slot] = make_float4(rad.x, rad.y, rad.z, 0.0f);
+                }
                 alive = false;
                 need = true;
             } else {
@@ -1988,9 +2018,12 @@ __global__ __launch_bounds__(64) void k_wf_shade(const RenderParams p) {
 // Adds each pixel's samples in index order (render.rs:99) and finishes the pixel (render.rs:103-110), or stores the sum.
 // A launch's samples may arrive in several batches (the buffer is bounded): `acc_io` carries the running sums from one
 // batch to the next, so the additions stay those of one loop over all samples.
-__global__ __launch_bounds__(256) void k_sum_samples(const float *samples, uint32_t n_samples, float *acc_io, uint32_t first_batch,
-                                                     uint32_t last_batch, uint32_t spp, uint32_t n_pixels, float *sum_rgba,
-                                                     uint8_t *rgba8, float *mean_rgb) {
+// A record whose fourth word has its top bit set is an escaping path's direction plus its packed attenuation chain
+// (k_render_bvh_sp): SkyMap::sample (backgrounds.rs:84-92), the chain product (render.rs:52) and the clamp (render.rs:95-97)
+// are evaluated here, by full waves.
+__global__ __launch_bounds__(256) void k_sum_samples(const RenderParams p, const float *samples, uint32_t n_samples, float *acc_io,
+                                                     uint32_t first_batch, uint32_t last_batch, uint32_t spp, uint32_t n_pixels,
+                                                     float *sum_rgba, uint8_t *rgba8, float *mean_rgb) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_pixels) return;
     V3 acc = mk(0.0f, 0.0f, 0.0f);
@@ -1999,9 +2032,38 @@ __global__ __launch_bounds__(256) void k_sum_samples(const float *samples, uint3
         acc = mk(c.x, c.y, c.z);
     }
     const float4 *src = reinterpret_cast<const float4 *>(samples) + i;
-    for (uint32_t k = 0; k < n_samples; k++) {
-        const float4 v = src[(uint64_t)k * n_pixels];
-        acc = add(acc, mk(v.x, v.y, v.z));
+    if (p.bg_kind != 2u) { // no deferred records without a SkyMap
+        for (uint32_t k = 0; k < n_samples; k++) {
+            const float4 v = src[(uint64_t)k * n_pixels];
+            acc = add(acc, mk(v.x, v.y, v.z));
+        }
+    } else {
+        // four samples at a time: their loads, then their texel gathers, are issued together; the additions stay in index order
+        for (uint32_t k = 0; k < n_samples; k += 4u) {
+            float4 v[4], tx[4];
+#pragma unroll
+            for (uint32_t j = 0; j < 4u; j++)
+                v[j] = k + j < n_samples ? src[(uint64_t)(k + j) * n_pixels] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+#pragma unroll
+            for (uint32_t j = 0; j < 4u; j++) {
+                const bool deferred = (__float_as_uint(v[j].w) & 0x80000000u) != 0u;
+                const unsigned long long ti = deferred ? sky_texel_index(p, mk(v[j].x, v[j].y, v[j].z)) : 0ull;
+                tx[j] = reinterpret_cast<const float4 *>(p.sky)[ti];
+            }
+#pragma unroll
+            for (uint32_t j = 0; j < 4u; j++) {
+                if (k + j >= n_samples) break;
+                V3 rad = mk(v[j].x, v[j].y, v[j].z);
+                const uint32_t w = __float_as_uint(v[j].w);
+                if (w & 0x80000000u) {
+                    V3 term = mk(tx[j].x, tx[j].y, tx[j].z);
+                    for (uint32_t c = (w >> 24) & 3u; c > 0u; c--) // innermost attenuation first: the chain's last entry
+                        term = mul(material_rgb(p, nullptr, (w >> (8u * (c - 1u))) & 255u), term);
+                    rad = clamp_radiance(p, term);
+                }
+                acc = add(acc, rad);
+            }
+        }
     }
     if (!last_batch) {
         reinterpret_cast<float4 *>(acc_io)[i] = make_float4(acc.x, acc.y, acc.z, 0.0f);
@@ -2176,9 +2238,9 @@ hipError_t wf_intersect_attributes(const RenderParams &p, int *vgprs) {
     return e;
 }
 
-hipError_t launch_sum_samples(const float *samples, uint32_t n_samples, float *acc_io, bool first_batch, bool last_batch, uint32_t spp,
+hipError_t launch_sum_samples(const RenderParams &p, const float *samples, uint32_t n_samples, float *acc_io, bool first_batch, bool last_batch, uint32_t spp,
                               uint32_t n_pixels, float *sum_rgba, uint8_t *rgba8, float *mean_rgb, hipStream_t stream) {
-    hipLaunchKernelGGL(k_sum_samples, dim3((n_pixels + 255u) / 256u), dim3(256), 0, stream, samples, n_samples, acc_io,
+    hipLaunchKernelGGL(k_sum_samples, dim3((n_pixels + 255u) / 256u), dim3(256), 0, stream, p, samples, n_samples, acc_io,
                        first_batch ? 1u : 0u, last_batch ? 1u : 0u, spp, n_pixels, sum_rgba, rgba8, mean_rgb);
     return hipGetLastError();
 }

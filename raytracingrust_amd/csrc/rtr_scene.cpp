@@ -603,7 +603,7 @@ int build_flat_scene(const rtr_scene_desc &desc, FlatScene &out, std::string &er
     std::vector<uint32_t> obj_ref(desc.n_objects, REF_NONE);
     std::vector<Box> obj_box(desc.n_objects);
     std::vector<uint32_t> obj_height(desc.n_objects, 0);
-    Flattener fl{desc, meshes, scene_walk, out, obj_ref, obj_box, obj_height, obj_leaf_base, vol_leaf_base};
+    Flattener fl{desc, meshes, scene_walk, out, obj_ref, obj_box, obj_height, obj_leaf_base, vol_leaf_base, true, {}};
     fl.leaf_pairs = opts.leaf_pairs;
     Flattener::Emitted root = fl.emit_scene_node(scene_walk.root);
     out.root_ref = root.ref;
