@@ -66,7 +66,7 @@ def parse_args(argv=None):
     ap.add_argument("--split", choices=["samples", "tiles"], default="samples",
                     help="multi-GPU decomposition: split the samples of every pixel over the ranks (default: full "
                          "grids of short waves, perfect balance) or 8x8 tiles round-robin (bit-identical to one GPU)")
-    ap.add_argument("--mesh-tree", choices=["reference", "sah"], default="reference",
+    ap.add_argument("--mesh-tree", choices=["reference", "sah", "lbvh"], default="reference",
                     help="mesh subtrees: the reference's median split (parity) or the binned-SAH rebuild (faster walk)")
     ap.add_argument("--scene-tree", choices=["reference", "sah"], default="reference",
                     help="scene-level tree over the objects: the reference's median split (parity) or binned SAH")
@@ -150,6 +150,8 @@ def workload_key(args, W, H):
     key = f"{name}_{W}x{H}_{args.spp}spp"
     if args.mesh_tree == "sah" or args.scene_tree == "sah":
         key += "_sah"
+    if args.mesh_tree == "lbvh":
+        key += "_lbvh"
     if args.tree_kernel:
         key += "_" + args.tree_kernel
     return key
@@ -396,6 +398,7 @@ def main():
                 "msamples_per_s": round(W * H * args.spp * args.steps / elapsed / 1e6, 2),
                 "segments_per_frame": int(total_segments / max(args.steps, 1)),
                 "kernel_ms": round(kernel_ms, 4), "vgprs": int(stats.vgprs), "lds_bytes_per_wave": int(stats.lds_bytes),
+                "upload_ms": round(float(stats.upload_ms), 3),
                 "parity": "unpinned (the reference holds no fixtures and cannot be built here); checked against oracle/",
             },
             "roofline": roofline_block(prof, prof_status, my_integrate_ms, alg_bytes, r.kernel_name()),

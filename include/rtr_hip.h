@@ -200,6 +200,11 @@ int rtr_abi_version(void);
  *                 (SURVEY section 8f N1).  Closest hits are the same and exact-t ties still resolve by the reference's
  *                 depth-first leaf rank; only ulp-level box-boundary cases can differ.  About half the traversal work
  *                 on assets/house.obj.
+ *               = "lbvh": mesh subtrees are built ON THE DEVICE: Morton codes of the triangle boxes'
+ *                 centroids, a radix sort, Karras' parallel radix tree, one bottom-up pass for the boxes -- instead of the
+ *                 host's O(n log^2 n) median-split build; for large or changing meshes.  Same closest hits; exact-t ties
+ *                 resolve by triangle index (the reference's depth-first rank is not computed); box-boundary grazes can
+ *                 differ as with "sah".  Needs a device-bound context.  Meshes that bound a Volume keep the reference tree.
  *   "scene_tree" = "reference" (default) | "sah": the same choice for the scene-level tree over the objects; honoured
  *                 only for scenes without Volume objects whose object boxes all have positive extent.
  *   "leaf_pairs" = "on" (default) | "off": a Split node whose two children are leaves of one type with consecutive

@@ -15,7 +15,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "_lib")
 LIB_PATH = os.path.join(LIB_DIR, "librtr_hip.so")
 
-SOURCES = ["rtr_api.cpp", "rtr_scene.cpp", "rtr_kernels.hip"]
+SOURCES = ["rtr_api.cpp", "rtr_scene.cpp", "rtr_kernels.hip", "rtr_lbvh.hip"]
 HEADERS = ["rtr_device.h", "rtr_scene.h", os.path.join("..", "..", "include", "rtr_hip.h")]
 
 # -ffp-contract=off + correctly rounded divide/sqrt: the kernels must round like the reference's f32 code
@@ -35,7 +35,7 @@ def kernel_sha() -> str:
     import hashlib
 
     h = hashlib.sha256()
-    for name in ("rtr_kernels.hip", "rtr_device.h", "rtr_api.cpp"):
+    for name in ("rtr_kernels.hip", "rtr_device.h", "rtr_api.cpp"):  # (rtr_lbvh.hip builds trees, it does not render)
         with open(os.path.join(CSRC, name), "rb") as fh:
             h.update(fh.read())
     h.update(" ".join(FLAGS).encode())

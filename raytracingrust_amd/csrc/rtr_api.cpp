@@ -30,6 +30,8 @@ hipError_t launch_sum_samples(const RenderParams &p, const float *samples, uint3
                               uint32_t n_pixels, float *sum_rgba, uint8_t *rgba8, float *mean_rgb, hipStream_t stream);
 hipError_t launch_selftest_sqrt(unsigned long long *d_mismatches, hipStream_t stream);
 hipError_t launch_debug_fault(unsigned long long *fault, hipStream_t stream);
+hipError_t lbvh_build(const float *d_boxes, uint32_t n, const float bounds_min[3], const float bounds_max[3], DevNode *d_nodes_out,
+                      uint32_t node_base, uint32_t leaf_base, uint32_t *d_height, hipStream_t stream);
 hipError_t launch_wf_generate(const RenderParams &p, uint32_t batch_samples, hipStream_t stream);
 hipError_t launch_wf_intersect(const RenderParams &p, uint32_t grid, hipStream_t stream);
 hipError_t launch_wf_shade(const RenderParams &p, uint32_t grid, hipStream_t stream);
@@ -494,11 +496,40 @@ int rtr_upload_scene(rtr_context *ctx, const rtr_scene_desc *scene) {
     std::string err;
     int rc = rtr::build_flat_scene(*scene, flat, err, ctx->build_options);
     if (rc != RTR_OK) return fail(ctx, rc, err);
+    if (ctx->device < 0 && !flat.lbvh_jobs.empty())
+        return fail(ctx, RTR_ERR_NO_DEVICE, "mesh_tree = \"lbvh\" builds the mesh trees on the device: not available in a host-only context");
     if (ctx->device >= 0) {
         RTR_HIP_TRY(ctx, hipSetDevice(ctx->device));
         RTR_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         free_scene(ctx);
         if ((rc = upload_vec(ctx, flat.nodes, &ctx->d_nodes))) return rc;
+        if (!flat.lbvh_jobs.empty()) { // device-side builder (rtr_lbvh.hip): writes the reserved node records in place
+            void *d_boxes = nullptr;
+            uint32_t *d_height = nullptr;
+            uint64_t scratch = ctx->device_bytes;
+            if ((rc = upload_vec(ctx, flat.lbvh_boxes, &d_boxes))) return rc;
+            ctx->device_bytes = scratch; // (freed below: not part of the resident scene)
+            hipError_t e = hipMalloc((void **)&d_height, sizeof(uint32_t));
+            if (e == hipSuccess) e = hipMemset(d_height, 0, sizeof(uint32_t));
+            for (size_t j = 0; e == hipSuccess && j < flat.lbvh_jobs.size(); j++) {
+                const rtr::LbvhJob &job = flat.lbvh_jobs[j];
+                e = rtr::lbvh_build(static_cast<const float *>(d_boxes) + 6ull * job.box_offset, job.n_tris, job.bounds_min, job.bounds_max,
+                                    static_cast<rtr::DevNode *>(ctx->d_nodes) + job.node_base, job.node_base, job.leaf_base, d_height, ctx->stream);
+            }
+            uint32_t height = 0;
+            if (e == hipSuccess) e = hipMemcpy(&height, d_height, sizeof height, hipMemcpyDeviceToHost);
+            if (e == hipSuccess) e = hipMemcpy(flat.nodes.data(), ctx->d_nodes, flat.nodes.size() * sizeof(rtr::DevNode), hipMemcpyDeviceToHost);
+            if (d_boxes) (void)hipFree(d_boxes);
+            if (d_height) (void)hipFree(d_height);
+            if (e != hipSuccess) return fail_hip(ctx, e, "device-side BVH build");
+            // the walk's stack bound: the host part counted a device-built subtree as a leaf
+            flat.stack_depth += height;
+            flat.tree_height += height;
+            flat.mesh_stack_depth = std::max(flat.mesh_stack_depth, height);
+            flat.mesh_height = std::max(flat.mesh_height, height);
+            flat.lbvh_boxes.clear();
+            flat.lbvh_boxes.shrink_to_fit();
+        }
         if ((rc = upload_vec(ctx, flat.leaf_hot, &ctx->d_leaf_hot))) return rc;
         if ((rc = upload_vec(ctx, flat.leaf_cold, &ctx->d_leaf_cold))) return rc;
         if ((rc = upload_vec(ctx, flat.lin_spheres, &ctx->d_lin))) return rc;
@@ -520,8 +551,10 @@ int rtr_set_option(rtr_context *ctx, const char *name, const char *value) {
     const std::string n(name), v(value);
     if (n == "mesh_tree") { // takes effect at the next rtr_upload_scene
         if (v == "reference") ctx->build_options.sah_mesh_trees = false;
-        else if (v == "sah") ctx->build_options.sah_mesh_trees = true;
-        else return fail(ctx, RTR_ERR_INVALID_ARGUMENT, "mesh_tree must be \"reference\" or \"sah\"");
+        else if (v == "sah") { ctx->build_options.sah_mesh_trees = true; ctx->build_options.lbvh_mesh_trees = false; return RTR_OK; }
+        else if (v == "lbvh") { ctx->build_options.lbvh_mesh_trees = true; ctx->build_options.sah_mesh_trees = false; return RTR_OK; }
+        else return fail(ctx, RTR_ERR_INVALID_ARGUMENT, "mesh_tree must be \"reference\", \"sah\" or \"lbvh\"");
+        ctx->build_options.lbvh_mesh_trees = false;
         return RTR_OK;
     }
     if (n == "scene_tree") {

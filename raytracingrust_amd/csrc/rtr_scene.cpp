@@ -128,6 +128,8 @@ struct MeshBuild {
                                    // depth-first order -- exact-t ties resolve by it whichever tree is walked
     std::vector<DevLeafHot> hot;   // per triangle handle
     std::vector<DevLeafCold> cold; // per triangle handle
+    std::vector<Box> tri_boxes;    // per triangle handle (mesh.rs:201-213), kept for the device builder
+    bool lbvh = false;             // the subtree is built on the device (BuildOptions::lbvh_mesh_trees)
     Box bounds;                    // Mesh.bounds, mesh.rs:99-108
 };
 
@@ -321,6 +323,33 @@ struct Flattener {
         return {idx, n.box, 1 + std::max(l.height, r.height), false, 1 + std::max(l.pushes, r.pushes)};
     }
 
+    // A mesh whose subtree the device builds: leaf records in handle order, n_tris - 1 node records reserved, the job noted.
+    Emitted emit_lbvh_mesh(uint32_t object, const MeshBuild &mb, uint32_t leaf_base) {
+        const uint32_t n = (uint32_t)mb.hot.size();
+        for (uint32_t h = 0; h < n; h++) {
+            out.leaf_hot[leaf_base + h] = mb.hot[h];
+            DevLeafCold c = mb.cold[h];
+            c.object = object;
+            out.leaf_cold[leaf_base + h] = c;
+        }
+        LbvhJob job{};
+        job.node_base = (uint32_t)out.nodes.size();
+        job.n_tris = n;
+        job.leaf_base = leaf_base;
+        job.box_offset = out.lbvh_boxes.size() / 6u;
+        Box all = mb.tri_boxes[0];
+        for (const Box &bx : mb.tri_boxes) {
+            all = surround(all, bx);
+            for (int k = 0; k < 3; k++) out.lbvh_boxes.push_back(bx.mn[k]);
+            for (int k = 0; k < 3; k++) out.lbvh_boxes.push_back(bx.mx[k]);
+        }
+        for (int k = 0; k < 3; k++) { job.bounds_min[k] = all.mn[k]; job.bounds_max[k] = all.mx[k]; }
+        out.nodes.resize(out.nodes.size() + (n - 1u)); // written by the device builder
+        out.split_nodes += n - 1u;
+        out.lbvh_jobs.push_back(job);
+        return {job.node_base, all, 0, false, 0}; // height / pushes: measured on the device, added by rtr_upload_scene
+    }
+
     Emitted emit_object(uint32_t object) {
         const rtr_object &o = desc.objects[object];
         Emitted e;
@@ -331,8 +360,12 @@ struct Flattener {
         } else {
             const MeshBuild &mb = meshes[o.index];
             const uint32_t leaf_base = obj_leaf_base[object];
-            const Tree &t = mb.use_fast ? mb.fast : mb.tree;
-            e = emit_mesh_node(object, mb, t, t.root, leaf_base); // Mesh::hit = bvh_root.hit, mesh.rs:124-127
+            if (mb.lbvh) {
+                e = emit_lbvh_mesh(object, mb, leaf_base);
+            } else {
+                const Tree &t = mb.use_fast ? mb.fast : mb.tree;
+                e = emit_mesh_node(object, mb, t, t.root, leaf_base); // Mesh::hit = bvh_root.hit, mesh.rs:124-127
+            }
         }
         obj_ref[object] = e.ref;
         obj_box[object] = e.box;
@@ -441,6 +474,10 @@ int build_flat_scene(const rtr_scene_desc &desc, FlatScene &out, std::string &er
 
     // ---- meshes: Mesh::from_buffers + build_bvh (mesh.rs:78-121) ----
     std::vector<MeshBuild> meshes(desc.n_meshes);
+    std::vector<bool> bounds_a_volume(desc.n_meshes, false); // such meshes always get the reference's tree (nested walk)
+    for (uint32_t vi = 0; vi < desc.n_volumes; vi++)
+        if (desc.volumes[vi].boundary_kind == RTR_OBJ_MESH && desc.volumes[vi].boundary_mesh < desc.n_meshes)
+            bounds_a_volume[desc.volumes[vi].boundary_mesh] = true;
     for (uint32_t mi = 0; mi < desc.n_meshes; mi++) {
         const rtr_mesh &m = desc.meshes[mi];
         MeshBuild &mb = meshes[mi];
@@ -485,6 +522,17 @@ int build_flat_scene(const rtr_scene_desc &desc, FlatScene &out, std::string &er
         mb.bounds = mbounds;
         std::vector<uint32_t> handles(m.n_tris);
         std::iota(handles.begin(), handles.end(), 0u);
+        if (opts.lbvh_mesh_trees && m.n_tris >= 2 && !bounds_a_volume[mi]) {
+            // the device builds this subtree (rtr_lbvh.hip): no host build, leaf records in handle order
+            for (const Box &bx : tb)
+                for (int k = 0; k < 3; k++)
+                    if (bx.mn[k] != bx.mn[k] || bx.mx[k] != bx.mx[k]) { err = "NaN triangle box"; return RTR_ERR_NAN_CENTROID; }
+            mb.lbvh = true;
+            mb.tri_boxes = tb;
+            mb.rank.resize(m.n_tris);
+            std::iota(mb.rank.begin(), mb.rank.end(), 0u);
+            continue;
+        }
         Builder b(tb, mb.tree);
         mb.tree.root = b.build(handles, 0, handles.size());
         if (b.nan_seen) { err = "NaN triangle centroid: partial_cmp().unwrap() panics (bvh.rs:99,109,119)"; return RTR_ERR_NAN_CENTROID; }

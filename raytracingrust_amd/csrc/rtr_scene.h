@@ -13,7 +13,18 @@
 
 namespace rtr {
 
+// A mesh subtree the device builds (BuildOptions::lbvh_mesh_trees; csrc/rtr_lbvh.hip): the host reserves the mesh's
+// n_tris - 1 node records and hands over the per-triangle boxes; rtr_upload_scene runs the build and adds the measured
+// tree height to the stack bounds.
+struct LbvhJob {
+    uint32_t node_base, n_tris, leaf_base;
+    uint64_t box_offset; // first triangle's box in FlatScene::lbvh_boxes (6 floats per triangle)
+    float bounds_min[3], bounds_max[3]; // union of the triangle boxes: the subtree's root box
+};
+
 struct FlatScene {
+    std::vector<LbvhJob> lbvh_jobs;
+    std::vector<float> lbvh_boxes;
     std::vector<DevNode> nodes;
     std::vector<DevLeafHot> leaf_hot;
     std::vector<DevLeafCold> leaf_cold;
@@ -47,6 +58,10 @@ struct BuildOptions {
     // the same for the scene-level tree over the objects (used only for scenes without Volume objects whose object
     // boxes all have positive extent; otherwise the reference tree is kept)
     bool sah_scene_tree = false;
+    // Mesh subtrees are built ON THE DEVICE as linear BVHs (Morton sort + Karras radix tree, csrc/rtr_lbvh.hip) over the
+    // same triangle boxes; the host skips its O(n log^2 n) reference build for them.  Same closest hits; exact-t ties
+    // resolve by triangle handle (the reference's depth-first rank is not computed); needs a device-bound context.
+    bool lbvh_mesh_trees = false;
     // A Split whose children are two leaves of one type with consecutive ranks is stored in its parent as one
     // REF_PAIR ref (no node record): the same box test, the same two leaf tests in the same order, one
     // traversal step fewer.  Decisions are unchanged, so this stays on in the parity configuration.

@@ -753,3 +753,39 @@ def test_frames_of_different_seeds_are_not_pixel_permutations(gpu_renderer):
         idx = (np.arange(w * h) ^ d) % (w * h)
         assert not np.array_equal(a.reshape(-1, 3)[idx], b.reshape(-1, 3))
         assert not np.array_equal(np.sort(a.reshape(-1, 3), axis=0), np.sort(b.reshape(-1, 3), axis=0))
+
+
+# ---- N1: device-side BVH builder ------------------------------------------------------------------------------------
+@pytest.mark.parametrize("builder,w,h", [(lambda: house_scene(2), 160, 90), (lambda: monkey_scene(3, material=rt.Dielectric(1.5)), 128, 72),
+                                         (lambda: monkey_scene(2, bvh=False), 96, 54)])
+def test_device_built_mesh_trees_render_the_same_frame(builder, w, h):
+    """Option mesh_tree = "lbvh" (csrc/rtr_lbvh.hip): the mesh subtrees are linear BVHs built on the GPU (Morton sort,
+    Karras radix tree, bottom-up boxes) over the reference's per-triangle boxes.  A different tree must find the same
+    closest hits: same segment count as the oracle, frame within tolerance, at most a handful of last-bit pixel
+    differences (box-boundary grazes, as with the SAH trees), for every tree kernel; and the tree it reports must be a
+    valid one (n - 1 inner nodes per mesh, every leaf reachable once: checked by the frame being right)."""
+    scene = builder()
+    o_rgba, o_mean, o_st = pyoracle.OracleScene(scene, trig_mode=pyoracle.TRIG_POLY).render(w, h, 12, threads=0)
+    with rt.Renderer(0) as r:
+        r.upload_scene(scene)
+        ref_info = r.scene_info()
+        r.set_option("mesh_tree", "lbvh")
+        r.upload_scene(scene)
+        info = r.scene_info()
+        assert info.n_leaves == ref_info.n_leaves and info.n_nodes == ref_info.n_nodes  # binary trees over the same leaves
+        assert ref_info.tree_height <= info.tree_height <= 64
+        frames = {}
+        for kernel in ("auto", "wave", "resumable", "samples", "stream"):
+            r.set_option("tree_kernel", kernel)
+            rgba, mean = r.render(w, h, seed=12, want_rgba8=True, want_mean=True)
+            st = r.stats()
+            assert st.segments == o_st.segments, kernel
+            c = compare(mean, rgba, o_mean, o_rgba)
+            assert max(c["rel_l2"]) <= TOL and c["max_u8_delta"] <= 1 and c["mismatched_pixels"] <= 5, (kernel, c)
+            frames[kernel] = mean.view(np.uint32).copy()
+        for kernel in frames:
+            assert np.array_equal(frames[kernel], frames["auto"]), kernel  # one tree, one frame, whichever kernel walks it
+    with rt.Renderer(-1) as host_only:  # the device builder needs a device: a host-only context refuses
+        host_only.set_option("mesh_tree", "lbvh")
+        with pytest.raises(rt.RtrError):
+            host_only.upload_scene(scene)

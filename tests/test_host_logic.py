@@ -263,7 +263,7 @@ def test_options_are_validated_without_a_device():
     """rtr_set_option works on a host-only context: known names take their documented values, anything else is
     RTR_ERR_INVALID_ARGUMENT; tree options change the flattened tree, kernel options do not."""
     with rt.Renderer(-1) as r:
-        for name, good, bad in [("mesh_tree", ["reference", "sah"], "octree"), ("scene_tree", ["sah", "reference"], ""),
+        for name, good, bad in [("mesh_tree", ["reference", "sah", "lbvh", "reference"], "octree"), ("scene_tree", ["sah", "reference"], ""),
                                 ("leaf_pairs", ["off", "on"], "maybe"), ("tree_kernel", ["wave", "resumable", "samples", "stream", "auto"], "fast"),
                                 ("stream_flush", ["1", "64", "8"], "0"),
                                 ("samples_batch", ["3", "0"], "-1"),
