@@ -241,6 +241,10 @@ int rtr_abi_version(void);
  *                 rtr_segment_counts) returns RTR_ERR_HIP once: the frames rendered since the previous such call
  *                 are invalid.
  *   "debug_fault" = "off" (default) | "on": testing aid; launches set the fault word themselves.
+ *   "debug_alloc_limit" = "0" (default: none) | bytes: testing aid; scratch allocations above that size fail as if the
+ *                 device were out of memory (exercises the batch-halving retry of the "samples" / "stream" kernels).
+ * A scratch buffer that has to grow is freed and reallocated inside the call that needs it, which synchronises the
+ * device once; sizes are remembered, so steady-state frames of one size never reallocate.
  * Scratch shared by the launches of ONE context: the running sums and counters of sample chunks, the radiance buffer
  * and running sums of the "samples" tree kernel, the event / counter ring.  Issue a context's launches on one stream
  * (or order them with events); use one context per stream for concurrent frames. */

@@ -67,6 +67,7 @@ struct rtr_context {
     int sample_chunks = 0; // option "sample_chunks": 0 auto, else the number of pieces
     double chunk_timeout_s = 10.0; // option "chunk_timeout_ms": bound of a sample chunk's wait for its predecessor
     bool debug_fault = false;      // option "debug_fault": the next launches set bit 1 of the fault word
+    uint64_t debug_alloc_limit = 0; // option "debug_alloc_limit": scratch allocations above this many bytes fail (0: off)
     void *d_samples = nullptr; // k_render_bvh_sp: one float4 per (sample, pixel) of a launch
     uint32_t samples_batch = 0;  // option "samples_batch": samples per batch of that buffer (0: as many as 16 GiB hold)
     size_t samples_cap = 0;
@@ -171,6 +172,8 @@ int check_fault(rtr_context *ctx) {
 
 int ensure_scratch(rtr_context *ctx, void **buf, size_t *cap, size_t need) {
     if (*cap >= need) return RTR_OK;
+    if (ctx->debug_alloc_limit && need > ctx->debug_alloc_limit) // testing aid: behave as a device that is out of memory
+        return fail(ctx, RTR_ERR_OUT_OF_MEMORY, "scratch allocation above debug_alloc_limit");
     if (*buf) (void)hipFree(*buf);
     *buf = nullptr; *cap = 0;
     RTR_HIP_TRY(ctx, hipMalloc(buf, need));
@@ -599,6 +602,13 @@ int rtr_set_option(rtr_context *ctx, const char *name, const char *value) {
         const double ms = std::strtod(v.c_str(), &end);
         if (v.empty() || *end != '\0' || !(ms >= 0.0) || ms > 6.0e5) return fail(ctx, RTR_ERR_INVALID_ARGUMENT, "chunk_timeout_ms must be a number in [0, 600000]");
         ctx->chunk_timeout_s = ms * 1.0e-3;
+        return RTR_OK;
+    }
+    if (n == "debug_alloc_limit") { // testing aid: scratch buffers above this size cannot be allocated (0 = no limit)
+        char *end = nullptr;
+        const unsigned long long k = std::strtoull(v.c_str(), &end, 10);
+        if (v.empty() || *end != '\0') return fail(ctx, RTR_ERR_INVALID_ARGUMENT, "debug_alloc_limit must be a byte count");
+        ctx->debug_alloc_limit = k;
         return RTR_OK;
     }
     if (n == "debug_fault") { // testing aid: the following launches set the fault word

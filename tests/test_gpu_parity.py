@@ -789,3 +789,28 @@ def test_device_built_mesh_trees_render_the_same_frame(builder, w, h):
         host_only.set_option("mesh_tree", "lbvh")
         with pytest.raises(rt.RtrError):
             host_only.upload_scene(scene)
+
+
+def test_sample_buffers_shrink_when_the_device_is_short_of_memory():
+    """the per-sample radiance buffer (and the streaming kernels' path records) must not turn a shortage of
+    device memory into an error: a batch whose allocation fails is halved and retried, and any batch size gives the same
+    frame.  debug_alloc_limit makes allocations above a size fail."""
+    scene = house_scene(8)
+    w, h = 96, 54
+    with rt.Renderer(0) as r:
+        r.upload_scene(scene)
+        for kernel in ("samples", "stream"):
+            r.set_option("tree_kernel", kernel)
+            ref_rgba, ref_mean = r.render(w, h, seed=4, want_rgba8=True, want_mean=True)
+            seg = r.stats().segments
+        with rt.Renderer(0) as small:
+            small.upload_scene(scene)
+            small.set_option("tree_kernel", kernel)
+            # room for 3 samples of radiance ("samples") / 2 samples of path records ("stream"), not for all 8
+            small.set_option("debug_alloc_limit", str(w * h * 16 * 3 if kernel == "samples" else 1_000_000))
+            rgba, mean = small.render(w, h, seed=4, want_rgba8=True, want_mean=True)
+            assert small.stats().segments == seg
+            assert np.array_equal(rgba, ref_rgba) and np.array_equal(mean.view(np.uint32), ref_mean.view(np.uint32))
+            small.set_option("debug_alloc_limit", "1000")  # not even one sample fits: a clean error, not a crash
+            with pytest.raises(rt.RtrError):
+                small.render(w + 8, h, seed=4)
