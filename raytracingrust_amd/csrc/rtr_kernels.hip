@@ -1235,7 +1235,10 @@ template <uint32_t WORLD, uint32_t NS, uint32_t VOL, bool MESH>
 // 96 scalar registers: a wave's SGPRs come in 16-register granules out of 800 per SIMD, so the 105 the compiler would
 // take (sphere constants + camera + parameters) admit 7 waves per SIMD and 96 admit 8 -- the vector registers (62)
 // already allow 8.  Measured +2.4 % on the headline kernel, neutral on the tree kernels.
-__attribute__((amdgpu_num_sgpr(96)))
+#ifndef RTR_X_RENDER_SGPRS
+#define RTR_X_RENDER_SGPRS 96
+#endif
+__attribute__((amdgpu_num_sgpr(RTR_X_RENDER_SGPRS)))
 __global__ __launch_bounds__(64, RTR_X_WAVES_PER_EU) void k_render(const RenderParams p) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const uint32_t lane = threadIdx.x;
@@ -1476,7 +1479,7 @@ constexpr uint32_t kWalkUnroll = RTR_X_WALK_UNROLL;
 #define RTR_X_BVH_SGPRS 96
 #endif
 #ifndef RTR_X_BVH_WAVES
-#define RTR_X_BVH_WAVES 7 // 72 VGPRs without spills (the compiler takes 75 unasked): 7 waves per SIMD, +0 ... +5 %
+#define RTR_X_BVH_WAVES 6 // 80 VGPRs: the 7-wave budget (72) spills since the cull bound joined the walk's state (C4 +5 %, C3 +11 % at 6)
 #endif
 template <uint32_t VOL, bool MESH>
 __attribute__((amdgpu_num_sgpr(RTR_X_BVH_SGPRS)))
