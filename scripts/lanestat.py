@@ -38,5 +38,5 @@ for k, n in ((13, "lambertian"), (14, "metal"), (15, "emission"), (16, "dielectr
     print(f"  {n:10s} lanes per trip {c[k] / trips:6.2f}")
 print(f"  sampler: runs in {100.0 * c[20] / trips:.1f} % of trips, {c[18] / max(c[20], 1):.2f} wave iterations per run, "
       f"{c[19] / max(c[18], 1):.2f} lanes per iteration, {c[19] / trips:.2f} lane-iterations per trip")
-print(f"  done: block runs in {100.0 * c[22] / trips:.1f} % of trips with {c[21] / max(c[22], 1):.2f} lanes; "
-      f"chain replay {c[23] / max(c[22], 1):.2f} wave iterations per run, {c[24] / max(c[23], 1):.2f} lanes per iteration")
+print(f"  done: block (chain replay, clamp, accumulate, regenerate) runs in {100.0 * c[22] / trips:.1f} % of trips with "
+      f"{c[21] / max(c[22], 1):.2f} lanes")
