@@ -6,6 +6,7 @@
 //
 // Options: --bvh 0|1, --depth N, --mode Full|Clay|Random|Normal, --f32 file (raw mean radiance floats), --device N,
 //          --fast-trees (rebuild mesh and scene trees with the surface-area heuristic: same hits, faster walk),
+//          --device-trees (build the mesh trees on the GPU as linear BVHs: same hits, fast build, slower walk),
 //          --sky file.pfm (replace the scene's background by a SkyMap read from a colour Portable Float Map).
 #include <chrono>
 #include <cstdio>
@@ -44,7 +45,7 @@ int main(int argc, char **argv) {
     long spp = -1, depth = -1, bvh = -1;
     uint64_t seed = 0x5EED;
     int device = 0;
-    bool info = false, host_only = false, fast_trees = false;
+    bool info = false, host_only = false, fast_trees = false, device_trees = false;
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
         auto next = [&]() -> const char * { if (i + 1 >= argc) { std::fprintf(stderr, "missing value for %s\n", a.c_str()); std::exit(2); } return argv[++i]; };
@@ -64,6 +65,7 @@ int main(int argc, char **argv) {
         else if (a == "--info") info = true;
         else if (a == "--host-only") host_only = true;
         else if (a == "--fast-trees") fast_trees = true;
+        else if (a == "--device-trees") device_trees = true;
         else if (a == "--sky") sky = next();
         else { std::fprintf(stderr, "unknown option %s\n", a.c_str()); return 2; }
     }
@@ -80,6 +82,7 @@ int main(int argc, char **argv) {
                                 : mode == "Normal" ? rtr::RenderMode::Normal : rtr::RenderMode::Full;
         rtr::Renderer r(host_only ? -1 : device);
         if (fast_trees) { r.set_option("mesh_tree", "sah"); r.set_option("scene_tree", "sah"); }
+        if (device_trees) r.set_option("mesh_tree", "lbvh"); // mesh trees built on the GPU (csrc/rtr_lbvh.hip)
         r.upload(scene);
         if (info) {
             rtr_scene_info si = r.info();

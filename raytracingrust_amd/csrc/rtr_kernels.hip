@@ -1633,7 +1633,10 @@ __global__ __launch_bounds__(64, RTR_X_BVH_WAVES) void k_render_bvh(const Render
 // 6 waves per SIMD and 128 SGPRs: 80 VGPRs without the spills the 7-wave budget forces on this kernel (+4 ... 5 %)
 template <uint32_t VOL, bool MESH>
 __attribute__((amdgpu_num_sgpr(128)))
-__global__ __launch_bounds__(64, 6) void k_render_bvh_sp(const RenderParams p) {
+#ifndef RTR_X_SP_WAVES
+#define RTR_X_SP_WAVES 6
+#endif
+__global__ __launch_bounds__(64, RTR_X_SP_WAVES) void k_render_bvh_sp(const RenderParams p) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const uint32_t lane = threadIdx.x;
     const uint32_t chunk = blockIdx.x / p.tiles_launch, tidx = blockIdx.x - chunk * p.tiles_launch;
