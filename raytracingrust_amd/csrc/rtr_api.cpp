@@ -263,7 +263,17 @@ int launch_frame(rtr_context *ctx, const rtr_camera *camera, const rtr_settings 
     const uint32_t lds_mat_cap = (p.world == rtr::WORLD_LINEAR_SPHERES) ? 128u : RTR_BVH_LDS_MATERIALS;
     p.lds_materials = (p.n_materials > 0u && p.n_materials <= lds_mat_cap) ? p.n_materials : 0u;
     // dynamic LDS per wave: attenuation chain + traversal stack (refs + entry distances) + the tables
-    uint32_t lds_bytes = p.max_depth * 64u * 4u + p.stack_cap * 64u * rtr::stack_entry_bytes() + (p.sphere_regs + p.lds_materials) * 32u;
+    // The attenuation chain: a column of max_ray_depth entries per lane in LDS, or -- in the tree worlds, when
+    // max_ray_depth ids fit 32 bits (the all-ones code is the Clay id) -- one register.  The tree kernels' occupancy is
+    // bounded by LDS, so giving the chain's region back pays (house.obj: 6.8 -> 6.0 KB per wave, C4 +5 %); the sphere
+    // world has LDS to spare and the register form's variable shifts cost it 3 % (measured), so it keeps the LDS column.
+    {
+        uint32_t width = 1u;
+        while (width < 32u && ((1u << width) - 1u) < p.n_materials) width++;
+        p.chain_bits = (p.world != rtr::WORLD_LINEAR_SPHERES && width * p.max_depth <= 32u && width < 32u) ? width : 0u;
+        p.chain_lds = p.chain_bits ? 0u : p.max_depth;
+    }
+    uint32_t lds_bytes = p.chain_lds * 64u * 4u + p.stack_cap * 64u * rtr::stack_entry_bytes() + (p.sphere_regs + p.lds_materials) * 32u;
 #ifdef RTR_X_COOP_BALL
     if (p.sphere_regs) lds_bytes += rtr::coop_ball_lds_bytes(); // the wave-cooperative rejection sampler's scratch (experiment)
 #endif

@@ -18,6 +18,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "rtr_device.h"
 
 namespace rtr {
@@ -947,11 +949,43 @@ RTR_DEV V3 background(const RenderParams &p, const Ray &r) {
 // The attenuation chain of a path: the ids of the materials whose attenuation multiplies the terminal radiance, in
 // bounce order.  LdsChain: a per-lane column of the wave's LDS, [entry][lane] (conflict-free).  GlobalChain: one u32 per
 // (entry, path) in HBM, [entry][path], for the streaming kernels whose paths outlive a kernel.
-struct LdsChain {
+struct LdsChain { // the sphere world's: LDS to spare, nothing to gain from the register form (measured: -2 ... -3 %)
     uint32_t *base;
     uint32_t lane, n;
+    RTR_DEV void init(uint32_t *lds_base, uint32_t lane_id, uint32_t) { base = lds_base; lane = lane_id; n = 0u; }
+    RTR_DEV void reset() { n = 0u; }
     RTR_DEV void push(uint32_t id) { base[n * 64u + lane] = id; n++; }
+    RTR_DEV uint32_t at(uint32_t j) const { return base[j * 64u + lane]; }
     RTR_DEV uint32_t pop() { n--; return base[n * 64u + lane]; }
+};
+struct PackChain { // the tree worlds'
+    uint32_t *base;
+    uint32_t lane, n;
+    // width != 0 (a wave-uniform choice of the host: RenderParams::chain_bits): the ids do not go through LDS at all but
+    // sit in `packed`, `width` bits each -- possible whenever max_ray_depth ids of the scene's material table fit 32
+    // bits (gui.rs scene: 3 x 3 bits).  The wave then needs no chain region in LDS, and LDS is what bounds the tree
+    // kernels' occupancy (house.obj: 6.8 -> 6.0 KB per wave, C4 +5 %).  All-ones is the Clay id.
+    uint32_t packed, width;
+    RTR_DEV void init(uint32_t *lds_base, uint32_t lane_id, uint32_t bits) { base = lds_base; lane = lane_id; width = bits; n = 0u; packed = 0u; }
+    RTR_DEV void reset() { n = 0u; packed = 0u; }
+    RTR_DEV void push(uint32_t id) {
+        if (width) packed |= (id == kChainClay ? (1u << width) - 1u : id) << (n * width);
+        else base[n * 64u + lane] = id;
+        n++;
+    }
+    RTR_DEV uint32_t at(uint32_t j) const {
+        if (width) {
+            const uint32_t mask = (1u << width) - 1u, code = (packed >> (j * width)) & mask;
+            return code == mask ? kChainClay : code;
+        }
+        return base[j * 64u + lane];
+    }
+    RTR_DEV uint32_t pop() {
+        n--;
+        const uint32_t id = at(n);
+        if (n == 0u) packed = 0u;
+        return id;
+    }
 };
 struct GlobalChain {
     uint32_t *base;
@@ -959,6 +993,7 @@ struct GlobalChain {
     uint32_t path, n;
     RTR_DEV void push(uint32_t id) { base[(uint64_t)n * stride + path] = id; n++; }
     RTR_DEV uint32_t pop() { n--; return base[(uint64_t)n * stride + path]; }
+    RTR_DEV void reset() { n = 0u; }
 };
 
 // f32::clamp(0, clamp_indirect) per channel with NaN staying NaN (render.rs:95-97)
@@ -1250,9 +1285,9 @@ __global__ __launch_bounds__(64, RTR_X_WAVES_PER_EU) void k_render(const RenderP
     __builtin_amdgcn_s_waitcnt(0);
     __builtin_amdgcn_wave_barrier();
 #endif
-    LdsChain chain;
-    chain.base = lds; chain.lane = lane; chain.n = 0u;
-    uint32_t *stk_ref = lds + p.max_depth * 64u;
+    typename std::conditional<WORLD == WORLD_LINEAR_SPHERES, LdsChain, PackChain>::type chain;
+    chain.init(lds, lane, p.chain_bits);
+    uint32_t *stk_ref = lds + p.chain_lds * 64u;
     StackT *stk_t = reinterpret_cast<StackT *>(stk_ref + p.stack_cap * 64u);
     uint32_t *lds_spheres = reinterpret_cast<uint32_t *>(stk_t + p.stack_cap * 64u);
     uint32_t *lds_mat_base = lds_spheres + NS * 8u;
@@ -1335,7 +1370,7 @@ __global__ __launch_bounds__(64, RTR_X_WAVES_PER_EU) void k_render(const RenderP
         // camera.rs:19-24
         ray.o = cam_o;
         ray.d = sub(sub(add(cam_llc, scale(cam_h, u)), scale(cam_v, v)), cam_o);
-        depth = 0; chain.n = 0u;
+        depth = 0; chain.reset();
     };
     if (s < spp) start_sample(s);
 
@@ -1489,9 +1524,9 @@ __global__ __launch_bounds__(64, RTR_X_BVH_WAVES) void k_render_bvh(const Render
     const uint32_t chunk = blockIdx.x / p.tiles_launch, tidx = blockIdx.x - chunk * p.tiles_launch;
     const uint32_t tile = tidx * p.n_shards + p.shard;
     if (tile >= p.tiles_total) return;
-    LdsChain chain;
-    chain.base = lds; chain.lane = lane; chain.n = 0u;
-    uint32_t *stk_ref = lds + p.max_depth * 64u;
+    PackChain chain;
+    chain.init(lds, lane, p.chain_bits);
+    uint32_t *stk_ref = lds + p.chain_lds * 64u;
     StackT *stk_t = reinterpret_cast<StackT *>(stk_ref + p.stack_cap * 64u);
     uint32_t *lds_mat_base = reinterpret_cast<uint32_t *>(stk_t + p.stack_cap * 64u);
     const uint32_t *lds_mats = p.lds_materials ? lds_mat_base : nullptr;
@@ -1541,7 +1576,7 @@ __global__ __launch_bounds__(64, RTR_X_BVH_WAVES) void k_render_bvh(const Render
         }
         ray.o = cam_o;
         ray.d = sub(sub(add(cam_llc, scale(cam_h, u)), scale(cam_v, v)), cam_o);
-        depth = 0; chain.n = 0u;
+        depth = 0; chain.reset();
     };
 
     // the walk's per-lane state (world_hit + traverse of k_render, unrolled into the loop below)
@@ -1647,9 +1682,9 @@ __global__ __launch_bounds__(64, RTR_X_SP_WAVES) void k_render_bvh_sp(const Rend
     __builtin_amdgcn_s_waitcnt(0);
     __builtin_amdgcn_wave_barrier();
 #endif
-    LdsChain chain;
-    chain.base = lds; chain.lane = lane; chain.n = 0u;
-    uint32_t *stk_ref = lds + p.max_depth * 64u;
+    PackChain chain;
+    chain.init(lds, lane, p.chain_bits);
+    uint32_t *stk_ref = lds + p.chain_lds * 64u;
     StackT *stk_t = reinterpret_cast<StackT *>(stk_ref + p.stack_cap * 64u);
     uint32_t *lds_mat_base = reinterpret_cast<uint32_t *>(stk_t + p.stack_cap * 64u);
     const uint32_t *lds_mats = p.lds_materials ? lds_mat_base : nullptr;
@@ -1689,7 +1724,7 @@ __global__ __launch_bounds__(64, RTR_X_SP_WAVES) void k_render_bvh_sp(const Rend
         }
         ray.o = cam_o;
         ray.d = sub(sub(add(cam_llc, scale(cam_h, u)), scale(cam_v, v)), cam_o);
-        depth = 0; chain.n = 0u;
+        depth = 0; chain.reset();
     };
 
     // the walk's per-lane state (world_hit + traverse of k_render, unrolled into the loop below)
@@ -1778,13 +1813,13 @@ __global__ __launch_bounds__(64, RTR_X_SP_WAVES) void k_render_bvh_sp(const Rend
                 uint32_t packed = 0x80000000u | (chain.n << 24);
                 bool fits = sky && chain.n <= 3u;
                 for (uint32_t j = 0; fits && j < chain.n; j++) {
-                    const uint32_t id = chain.base[j * 64u + lane];
+                    const uint32_t id = chain.at(j);
                     fits = id < 256u;
                     packed |= id << (8u * j);
                 }
                 if (fits) {
                     reinterpret_cast<float4 *>(p.samples)[slot] = make_float4(term.x, term.y, term.z, __uint_as_float(packed));
-                    chain.n = 0u;
+                    chain.reset();
                 } else {
                     if (sky) term = background(p, ray);
                     const V3 rad = sample_radiance(p, lds_mats, chain, term);
