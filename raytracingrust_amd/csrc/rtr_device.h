@@ -95,7 +95,8 @@ struct RenderParams {
     float root_box[6];
     uint32_t stack_cap; // entries per lane
     uint32_t chain_bits; // != 0: a path's attenuation chain is kept in one register, this many bits per material id
-    uint32_t chain_lds;  // entries per lane of the LDS chain region: max_depth, or 0 with chain_bits
+    uint32_t chain_lds;  // words per lane of the LDS chain region: max_depth ids (3 * max_depth in the sphere world, which keeps
+                         // the attenuations themselves), or 0 with chain_bits
     uint32_t sphere_regs;   // linear sphere world: spheres held in scalar registers (0 = generic loop)
     uint32_t lds_materials; // number of material records staged in LDS (0 = read from HBM/L1)
     uint32_t has_meshes;    // the scene holds triangles: tree kernels instantiated with the unconditional slab tests

@@ -950,15 +950,27 @@ RTR_DEV V3 background(const RenderParams &p, const Ray &r) {
 // bounce order.  LdsChain: a per-lane column of the wave's LDS, [entry][lane] (conflict-free).  GlobalChain: one u32 per
 // (entry, path) in HBM, [entry][path], for the streaming kernels whose paths outlive a kernel.
 struct LdsChain { // the sphere world's: LDS to spare, nothing to gain from the register form (measured: -2 ... -3 %)
-    uint32_t *base;
+    // Holds the attenuations THEMSELVES (three floats per bounce, [entry][channel][lane]), not material ids: the replay
+    // is then one LDS round trip per entry instead of two dependent ones (id, then the material's colour), in the block of
+    // the loop that a quarter of the wave's cycles go to although it is a seventh of its instructions.
+    static constexpr bool kStoresRgb = true;
+    float *base;
     uint32_t lane, n;
-    RTR_DEV void init(uint32_t *lds_base, uint32_t lane_id, uint32_t) { base = lds_base; lane = lane_id; n = 0u; }
+    RTR_DEV void init(uint32_t *lds_base, uint32_t lane_id, uint32_t) { base = reinterpret_cast<float *>(lds_base); lane = lane_id; n = 0u; }
     RTR_DEV void reset() { n = 0u; }
-    RTR_DEV void push(uint32_t id) { base[n * 64u + lane] = id; n++; }
-    RTR_DEV uint32_t at(uint32_t j) const { return base[j * 64u + lane]; }
-    RTR_DEV uint32_t pop() { n--; return base[n * 64u + lane]; }
+    RTR_DEV void push(uint32_t, V3 rgb) {
+        float *e = base + n * 192u + lane;
+        e[0] = rgb.x; e[64] = rgb.y; e[128] = rgb.z;
+        n++;
+    }
+    RTR_DEV V3 pop_rgb(const RenderParams &, const uint32_t *) {
+        n--;
+        const float *e = base + n * 192u + lane;
+        return mk(e[0], e[64], e[128]);
+    }
 };
 struct PackChain { // the tree worlds'
+    static constexpr bool kStoresRgb = false;
     uint32_t *base;
     uint32_t lane, n;
     // width != 0 (a wave-uniform choice of the host: RenderParams::chain_bits): the ids do not go through LDS at all but
@@ -968,11 +980,12 @@ struct PackChain { // the tree worlds'
     uint32_t packed, width;
     RTR_DEV void init(uint32_t *lds_base, uint32_t lane_id, uint32_t bits) { base = lds_base; lane = lane_id; width = bits; n = 0u; packed = 0u; }
     RTR_DEV void reset() { n = 0u; packed = 0u; }
-    RTR_DEV void push(uint32_t id) {
+    RTR_DEV void push(uint32_t id, V3) {
         if (width) packed |= (id == kChainClay ? (1u << width) - 1u : id) << (n * width);
         else base[n * 64u + lane] = id;
         n++;
     }
+    RTR_DEV V3 pop_rgb(const RenderParams &p, const uint32_t *lds_mats) { return material_rgb(p, lds_mats, pop()); }
     RTR_DEV uint32_t at(uint32_t j) const {
         if (width) {
             const uint32_t mask = (1u << width) - 1u, code = (packed >> (j * width)) & mask;
@@ -988,11 +1001,13 @@ struct PackChain { // the tree worlds'
     }
 };
 struct GlobalChain {
+    static constexpr bool kStoresRgb = false;
     uint32_t *base;
     uint64_t stride; // paths per entry row
     uint32_t path, n;
-    RTR_DEV void push(uint32_t id) { base[(uint64_t)n * stride + path] = id; n++; }
+    RTR_DEV void push(uint32_t id, V3) { base[(uint64_t)n * stride + path] = id; n++; }
     RTR_DEV uint32_t pop() { n--; return base[(uint64_t)n * stride + path]; }
+    RTR_DEV V3 pop_rgb(const RenderParams &p, const uint32_t *lds_mats) { return material_rgb(p, lds_mats, pop()); }
     RTR_DEV void reset() { n = 0u; }
 };
 
@@ -1012,7 +1027,7 @@ RTR_DEV V3 clamp_radiance(const RenderParams &p, V3 term) {
 template <class Chain>
 RTR_DEV V3 sample_radiance(const RenderParams &p, const uint32_t *lds_mats, Chain &chain, V3 term) {
     while (chain.n > 0u) {
-        term = mul(material_rgb(p, lds_mats, chain.pop()), term);
+        term = mul(chain.pop_rgb(p, lds_mats), term);
     }
     return clamp_radiance(p, term);
 }
@@ -1207,7 +1222,11 @@ RTR_DEV bool shade_segment(const RenderParams &p, bool was_hit, const Hit &h, Ra
             ndir = sv;
         }
         if (scattered) {
-            if (mid != 0xFFFFFFFEu) chain.push(mid);
+            if (mid != 0xFFFFFFFEu) {
+                // (the colour is re-read from the table rather than kept live across the sampler: 13 VGPRs)
+                if constexpr (Chain::kStoresRgb) chain.push(mid, material_rgb(p, lds_mats, mid));
+                else chain.push(mid, mk(0.0f, 0.0f, 0.0f));
+            }
             ray.o = h.point;
             ray.d = ndir;
             depth++;
@@ -1274,7 +1293,9 @@ template <uint32_t WORLD, uint32_t NS, uint32_t VOL, bool MESH>
 #define RTR_X_RENDER_SGPRS 96
 #endif
 __attribute__((amdgpu_num_sgpr(RTR_X_RENDER_SGPRS)))
-__global__ __launch_bounds__(64, RTR_X_WAVES_PER_EU) void k_render(const RenderParams p) {
+// (the sphere world at a 7-wave register budget: the compiler would take 77 VGPRs unasked -- 6 waves, 15.4 ms on the
+// headline frame -- and fits 65 without spilling when told to -- 7 waves, 14.7 ms)
+__global__ __launch_bounds__(64, WORLD == WORLD_LINEAR_SPHERES ? 7 : RTR_X_WAVES_PER_EU) void k_render(const RenderParams p) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const uint32_t lane = threadIdx.x;
     const uint32_t chunk = blockIdx.x / p.tiles_launch, tidx = blockIdx.x - chunk * p.tiles_launch;
@@ -1287,7 +1308,7 @@ __global__ __launch_bounds__(64, RTR_X_WAVES_PER_EU) void k_render(const RenderP
 #endif
     typename std::conditional<WORLD == WORLD_LINEAR_SPHERES, LdsChain, PackChain>::type chain;
     chain.init(lds, lane, p.chain_bits);
-    uint32_t *stk_ref = lds + p.chain_lds * 64u;
+    uint32_t *stk_ref = lds + p.chain_lds * 64u; // (the sphere world's chain_lds counts three words per entry)
     StackT *stk_t = reinterpret_cast<StackT *>(stk_ref + p.stack_cap * 64u);
     uint32_t *lds_spheres = reinterpret_cast<uint32_t *>(stk_t + p.stack_cap * 64u);
     uint32_t *lds_mat_base = lds_spheres + NS * 8u;
