@@ -271,9 +271,13 @@ int launch_frame(rtr_context *ctx, const rtr_camera *camera, const rtr_settings 
         uint32_t width = 1u;
         while (width < 32u && ((1u << width) - 1u) < p.n_materials) width++;
         p.chain_bits = (p.world != rtr::WORLD_LINEAR_SPHERES && width * p.max_depth <= 32u && width < 32u) ? width : 0u;
-        p.chain_lds = p.chain_bits ? 0u : (p.world == rtr::WORLD_LINEAR_SPHERES ? 3u * p.max_depth : p.max_depth); // sphere world: rgb triples
+        p.chain_lds = p.chain_bits ? 0u : p.max_depth;
+        if (p.world == rtr::WORLD_LINEAR_SPHERES) { // the attenuations themselves (three words per entry) while that stays small
+            if (p.max_depth <= 16u) p.chain_lds = 3u * p.max_depth;
+            else p.chain_bits = 0xFFFFFFFFu; // ids
+        }
     }
-    uint32_t lds_bytes = p.chain_lds * 64u * 4u + p.stack_cap * 64u * rtr::stack_entry_bytes() + (p.sphere_regs + p.lds_materials) * 32u;
+    uint32_t lds_bytes = p.chain_lds * 64u * 4u + p.stack_cap * 64u * rtr::stack_entry_bytes() + (2u * p.sphere_regs + p.lds_materials) * 32u; // spheres, their materials' copies, the material table
 #ifdef RTR_X_COOP_BALL
     if (p.sphere_regs) lds_bytes += rtr::coop_ball_lds_bytes(); // the wave-cooperative rejection sampler's scratch (experiment)
 #endif

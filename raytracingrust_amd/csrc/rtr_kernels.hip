@@ -646,6 +646,7 @@ struct Hit {
     V3 point, normal;
     bool front_face;
     uint32_t material;
+    uint32_t slot; // sphere world with an LDS table: the winner's slot, which also addresses a copy of its material record
 };
 
 // HitRecord::new (ray.rs:39-54)
@@ -785,6 +786,7 @@ RTR_DEV bool world_hit(const RenderParams &p, const Ray &r, Hit &h, uint32_t *st
         RTR_LS(12, true)
         const float4 w = *reinterpret_cast<const float4 *>(lds_spheres + best * 8); // centre, radius
         h.material = lds_spheres[best * 8 + 5];
+        h.slot = (uint32_t)best;
         h.point = add(r.o, scale(r.d, closest));
         const V3 pc = sub(h.point, mk(w.x, w.y, w.z));
         V3 outward;
@@ -956,15 +958,24 @@ struct LdsChain { // the sphere world's: LDS to spare, nothing to gain from the 
     static constexpr bool kStoresRgb = true;
     float *base;
     uint32_t lane, n;
-    RTR_DEV void init(uint32_t *lds_base, uint32_t lane_id, uint32_t) { base = reinterpret_cast<float *>(lds_base); lane = lane_id; n = 0u; }
+    bool ids; // wave-uniform (RenderParams::chain_bits == 0xFFFFFFFF): fall back to one id per entry when three words per
+              // entry would not fit LDS (max_ray_depth above 16; the reference allows 255)
+    RTR_DEV void init(uint32_t *lds_base, uint32_t lane_id, uint32_t bits) {
+        base = reinterpret_cast<float *>(lds_base); lane = lane_id; n = 0u; ids = bits == 0xFFFFFFFFu;
+    }
     RTR_DEV void reset() { n = 0u; }
-    RTR_DEV void push(uint32_t, V3 rgb) {
-        float *e = base + n * 192u + lane;
-        e[0] = rgb.x; e[64] = rgb.y; e[128] = rgb.z;
+    RTR_DEV void push(uint32_t id, V3 rgb) {
+        if (ids) {
+            reinterpret_cast<uint32_t *>(base)[n * 64u + lane] = id;
+        } else {
+            float *e = base + n * 192u + lane;
+            e[0] = rgb.x; e[64] = rgb.y; e[128] = rgb.z;
+        }
         n++;
     }
-    RTR_DEV V3 pop_rgb(const RenderParams &, const uint32_t *) {
+    RTR_DEV V3 pop_rgb(const RenderParams &p, const uint32_t *lds_mats) {
         n--;
+        if (ids) return material_rgb(p, lds_mats, reinterpret_cast<const uint32_t *>(base)[n * 64u + lane]);
         const float *e = base + n * 192u + lane;
         return mk(e[0], e[64], e[128]);
     }
@@ -1120,7 +1131,7 @@ RTR_DEV V3 coop_ball(const CoopBall &cb, bool need, Rng &rng, uint32_t lane, flo
 template <bool COOP = false, class Chain>
 RTR_DEV bool shade_segment(const RenderParams &p, bool was_hit, const Hit &h, Ray &ray, Rng &rng, const uint32_t *lds_mats,
                            Chain &chain, uint32_t lane, uint32_t &depth, V3 &term, bool active = true, const CoopBall *coop = nullptr,
-                           bool *defer_sky = nullptr) {
+                           bool *defer_sky = nullptr, const uint32_t *slot_mats = nullptr) {
     (void)lane; (void)coop;
     bool done = false;
     uint32_t kind = 7u, mid = 0u; // 7: no material to scatter from (inactive lane, miss, or a mode that returns at once)
@@ -1145,9 +1156,12 @@ RTR_DEV bool shade_segment(const RenderParams &p, bool was_hit, const Hit &h, Ra
         } else {
             // MixMaterial::scatter (materials.rs:148-157): xi >= factor -> first
             mid = h.material;
-            for (;;) {
+            for (bool first = true;; first = false) {
                 float4 q0, q1;
-                material_load(p, lds_mats, mid, q0, q1);
+                if (slot_mats && first) { // the hit sphere's material record, addressed by the sphere's slot: this read does not
+                    const float4 *m = reinterpret_cast<const float4 *>(slot_mats + h.slot * 8u); // wait for the material id
+                    q0 = m[0]; q1 = m[1];
+                } else material_load(p, lds_mats, mid, q0, q1);
                 kind = __float_as_uint(q1.x);
                 rgb = mk(q0.x, q0.y, q0.z);
                 param = q0.w;
@@ -1332,6 +1346,14 @@ __global__ __launch_bounds__(64, WORLD == WORLD_LINEAR_SPHERES ? 7 : RTR_X_WAVES
     }
     if (p.lds_materials)
         for (uint32_t i = lane; i < p.lds_materials * 8u; i += 64u) lds_mat_base[i] = reinterpret_cast<const uint32_t *>(p.materials)[i];
+    // sphere world: a copy of each sphere's material record next to the sphere table, addressed by the sphere's slot, so
+    // that the record of the hit sphere's material can be fetched together with the sphere's own record
+    uint32_t *slot_mats = nullptr;
+    if constexpr (NS > 0) {
+        slot_mats = lds_mat_base + p.lds_materials * 8u;
+        for (uint32_t i = lane; i < NS * 8u; i += 64u)
+            slot_mats[i] = reinterpret_cast<const uint32_t *>(p.materials)[p.lin_spheres[i >> 3].material * 8u + (i & 7u)];
+    }
     __builtin_amdgcn_s_waitcnt(0); // vmcnt(0) lgkmcnt(0): the tables are in LDS before any lane reads them
     __builtin_amdgcn_wave_barrier();
 
@@ -1420,7 +1442,7 @@ __global__ __launch_bounds__(64, WORLD == WORLD_LINEAR_SPHERES ? 7 : RTR_X_WAVES
         // Every lane stays in the loop until the wave's last path has ended: the rejection sampler inside shade_segment is
         // wave-cooperative, and a lane that has run out of samples still evaluates candidates for the others.
         CoopBall cb;
-        cb.lds = lds_mat_base + p.lds_materials * 8u;
+        cb.lds = lds_mat_base + p.lds_materials * 8u + NS * 8u;
         coop_ball_init(cb, lane);
         __builtin_amdgcn_s_waitcnt(0);
         __builtin_amdgcn_wave_barrier();
@@ -1455,7 +1477,7 @@ __global__ __launch_bounds__(64, WORLD == WORLD_LINEAR_SPHERES ? 7 : RTR_X_WAVES
         V3 term;
         const bool was_hit = world_hit<WORLD, NS, VOL, MESH>(p, ray, h, stk_ref, stk_t, lane, sr, lds_spheres, rng);
         RTR_STAMP(0)
-        done = shade_segment(p, was_hit, h, ray, rng, lds_mats, chain, lane, depth, term);
+        done = shade_segment(p, was_hit, h, ray, rng, lds_mats, chain, lane, depth, term, true, nullptr, nullptr, slot_mats);
         RTR_STAMP(1)
         RTR_LS(21, done)
         if (done) {
@@ -2276,6 +2298,7 @@ hipError_t launch_wf_generate(const RenderParams &p, uint32_t batch_samples, hip
 uint32_t wf_intersect_lds_bytes(const RenderParams &p) { return p.stack_cap * 64u * (4u + (uint32_t)sizeof(StackT)) + kWfRing * 4u; }
 uint32_t stack_entry_bytes() { return 4u + (uint32_t)sizeof(StackT); }
 uint32_t coop_ball_lds_bytes() { return kCoopWords * 4u; }
+// (the coop experiment's scratch, when built in, follows the sphere world's slot-material table)
 uint32_t wf_shade_lds_bytes(const RenderParams &p) { return (kWfRing + p.lds_materials * 8u) * 4u; }
 static uint32_t resident_waves(const void *fn, uint32_t lds_bytes) {
     int per_cu = 0, dev = 0, cus = 0;
