@@ -1237,9 +1237,12 @@ RTR_DEV bool shade_segment(const RenderParams &p, bool was_hit, const Hit &h, Ra
         }
         if (scattered) {
             if (mid != 0xFFFFFFFEu) {
-                // (the colour is re-read from the table rather than kept live across the sampler: 13 VGPRs)
+#ifdef RTR_X_CHAIN_REREAD // (re-reading the colour instead of keeping it live across the sampler)
                 if constexpr (Chain::kStoresRgb) chain.push(mid, material_rgb(p, lds_mats, mid));
                 else chain.push(mid, mk(0.0f, 0.0f, 0.0f));
+#else
+                chain.push(mid, rgb);
+#endif
             }
             ray.o = h.point;
             ray.d = ndir;
