@@ -1137,6 +1137,7 @@ RTR_DEV bool shade_segment(const RenderParams &p, bool was_hit, const Hit &h, Ra
     uint32_t kind = 7u, mid = 0u; // 7: no material to scatter from (inactive lane, miss, or a mode that returns at once)
     float param = 0.0f;
     V3 rgb = mk(0.8f, 0.8f, 0.8f);
+    float4 mq1 = make_float4(0.0f, 0.0f, 0.0f, 0.0f); // the material record's second half (Dielectric: 1/ir and the two r0^2)
     RTR_LS(17, active && !was_hit)
     if (active) {
         if (!was_hit) {
@@ -1165,6 +1166,7 @@ RTR_DEV bool shade_segment(const RenderParams &p, bool was_hit, const Hit &h, Ra
                 kind = __float_as_uint(q1.x);
                 rgb = mk(q0.x, q0.y, q0.z);
                 param = q0.w;
+                mq1 = q1;
                 if (kind != 4u) break;
                 mid = (rng_unit(rng) >= param) ? __float_as_uint(q1.y) : __float_as_uint(q1.z);
             }
@@ -1221,8 +1223,12 @@ RTR_DEV bool shade_segment(const RenderParams &p, bool was_hit, const Hit &h, Ra
         } else if (kind == 3u) { // Dielectric, materials.rs:111-138
             // 1/ir and the two Schlick r0^2 values are constants of the material, divided once on the host
             // (rtr_scene.cpp) into the record's spare words: re-read here rather than kept live across the sampler
+#ifdef RTR_X_DIELECTRIC_REREAD
             float4 dq0, dq1;
             material_load(p, lds_mats, mid, dq0, dq1);
+#else
+            const float4 dq1 = mq1;
+#endif
             const float ratio = h.front_face ? dq1.y : param;
             const float r0sq = h.front_face ? dq1.z : dq1.w;
             float cos_theta = fminf(dot(h.normal, neg(unit)), 1.0f);
