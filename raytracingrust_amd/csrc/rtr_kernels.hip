@@ -1037,6 +1037,13 @@ RTR_DEV V3 clamp_radiance(const RenderParams &p, V3 term) {
 // to its pixel
 template <class Chain>
 RTR_DEV V3 sample_radiance(const RenderParams &p, const uint32_t *lds_mats, Chain &chain, V3 term) {
+    if constexpr (Chain::kStoresRgb) {
+        // two entries per round: their reads are independent, so the replay costs one LDS round trip per PAIR of bounces
+        while (chain.n >= 2u) {
+            const V3 inner = chain.pop_rgb(p, lds_mats), outer = chain.pop_rgb(p, lds_mats);
+            term = mul(outer, mul(inner, term));
+        }
+    }
     while (chain.n > 0u) {
         term = mul(chain.pop_rgb(p, lds_mats), term);
     }
