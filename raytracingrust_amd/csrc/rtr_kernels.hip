@@ -1325,7 +1325,10 @@ template <uint32_t WORLD, uint32_t NS, uint32_t VOL, bool MESH>
 __attribute__((amdgpu_num_sgpr(RTR_X_RENDER_SGPRS)))
 // (the sphere world at a 7-wave register budget: the compiler would take 77 VGPRs unasked -- 6 waves, 15.4 ms on the
 // headline frame -- and fits 65 without spilling when told to -- 7 waves, 14.7 ms)
-__global__ __launch_bounds__(64, WORLD == WORLD_LINEAR_SPHERES ? 7 : RTR_X_WAVES_PER_EU) void k_render(const RenderParams p) {
+#ifndef RTR_X_SPHERE_WAVES
+#define RTR_X_SPHERE_WAVES 7 // (8: 64 VGPRs with 51 spilled SGPRs, 14.8 ms; 6: 15.4 ms)
+#endif
+__global__ __launch_bounds__(64, WORLD == WORLD_LINEAR_SPHERES ? RTR_X_SPHERE_WAVES : RTR_X_WAVES_PER_EU) void k_render(const RenderParams p) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const uint32_t lane = threadIdx.x;
     const uint32_t chunk = blockIdx.x / p.tiles_launch, tidx = blockIdx.x - chunk * p.tiles_launch;
