@@ -240,6 +240,8 @@ int rtr_abi_version(void);
  *                 fault word and the next synchronising call (rtr_render*, rtr_get_stats, rtr_kernel_times_ms,
  *                 rtr_segment_counts) returns RTR_ERR_HIP once: the frames rendered since the previous such call
  *                 are invalid.
+ *   "sky_filter" = "nearest" (default: SkyMap::sample, backgrounds.rs:84-92) | "bilinear": interpolate the four texels
+ *                 around the direction (longitude wraps, latitude clamps).  An extension, not reference behaviour.
  *   "debug_fault" = "off" (default) | "on": testing aid; launches set the fault word themselves.
  *   "debug_alloc_limit" = "0" (default: none) | bytes: testing aid; scratch allocations above that size fail as if the
  *                 device were out of memory (exercises the batch-halving retry of the "samples" / "stream" kernels).

@@ -44,6 +44,7 @@ def lib():
         L.or_set_camera.argtypes = [C.c_void_p, _f3, _f3, _f3, C.c_float, C.c_float]
         L.or_set_settings.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_float, C.c_int, C.c_int, C.c_int]
         L.or_set_trig_mode.argtypes = [C.c_void_p, C.c_int]
+        L.or_set_sky_filter.argtypes = [C.c_void_p, C.c_int]
         L.or_set_background_uniform.argtypes = [C.c_void_p, _f3]
         L.or_set_background_gradient.argtypes = [C.c_void_p, _f3, _f3]
         L.or_set_background_skymap.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]
@@ -82,7 +83,7 @@ class OracleError(RuntimeError):
 class OracleScene:
     """Builds an or_scene from a raytracingrust_amd.Scene (the same object the HIP path is fed)."""
 
-    def __init__(self, scene, trig_mode: int = TRIG_LIBM):
+    def __init__(self, scene, trig_mode: int = TRIG_LIBM, sky_bilinear: bool = False):
         from raytracingrust_amd import scene as S  # the scene *model* only: plain containers, no numerics
         L = lib()
         self._L = L
@@ -93,6 +94,7 @@ class OracleScene:
         L.or_set_settings(self._s, st.samples_per_pixel, st.max_ray_depth, float(np.float32(st.clamp_indirect)),
                           int(st.enable_multithreading), int(st.enable_bvh_tree), int(st.mode))
         L.or_set_trig_mode(self._s, trig_mode)
+        L.or_set_sky_filter(self._s, 1 if sky_bilinear else 0)
         bg = scene.background
         if isinstance(bg, S.UniformBackground):
             L.or_set_background_uniform(self._s, f3(bg.color))

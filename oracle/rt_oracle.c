@@ -222,6 +222,7 @@ struct or_scene {
     uint32_t samples_per_pixel; uint32_t max_ray_depth; float clamp_indirect;
     int enable_multithreading, enable_bvh_tree, mode;
     int trig_mode;
+    int sky_bilinear; /* or_set_sky_filter: an opt-in that is NOT reference behaviour (SkyMap::sample takes the nearest texel) */
     /* background */
     int bg_kind; col bg_a, bg_b; col *sky; uint32_t sky_w, sky_h;
     object_t *objects; int n_objects, cap_objects;
@@ -647,6 +648,24 @@ static col background_sample(const or_scene *sc, const ray_t *ray, tctx_t *tc) {
         float sy = or_atan2(-d.z, d.x, sc->trig_mode) + OR_PI;
         float u = sx / OR_PI;
         float v = sy / (2.0f * OR_PI);
+        if (sc->sky_bilinear) { /* opt-in extension, the same arithmetic as csrc/rtr_kernels.hip sky_bilinear */
+            float fx = v * (float)sc->sky_w - 0.5f, fy = u * (float)sc->sky_h - 0.5f;
+            if (!(fx == fx)) fx = 0.0f;
+            if (!(fy == fy)) fy = 0.0f;
+            float x0f = floorf(fx), r0f = floorf(fy);
+            float tx = fx - x0f, ty = fy - r0f;
+            int64_t w = (int64_t)sc->sky_w, h = (int64_t)sc->sky_h;
+            int64_t x0 = (int64_t)x0f, r0 = (int64_t)r0f;
+            int64_t x1 = x0 + 1, r1 = r0 + 1;
+            x0 = ((x0 % w) + w) % w; x1 = ((x1 % w) + w) % w;           /* longitude wraps */
+            r0 = r0 < 0 ? 0 : (r0 > h - 1 ? h - 1 : r0); r1 = r1 < 0 ? 0 : (r1 > h - 1 ? h - 1 : r1); /* latitude clamps */
+            int64_t y0 = h - 1 - r0, y1 = h - 1 - r1;
+            col t00 = sc->sky[x0 + y0 * w], t01 = sc->sky[x1 + y0 * w], t10 = sc->sky[x0 + y1 * w], t11 = sc->sky[x1 + y1 * w];
+            float ux = 1.0f - tx, uy = 1.0f - ty;
+            col a = col_add(col_scale(t00, ux), col_scale(t01, tx));
+            col b = col_add(col_scale(t10, ux), col_scale(t11, tx));
+            return col_add(col_scale(a, uy), col_scale(b, ty));
+        }
         uint64_t x = sat_usize(v * (float)sc->sky_w) % sc->sky_w;
         uint64_t y = sc->sky_h - 1 - sat_usize(u * (float)sc->sky_h) % sc->sky_h;
         return sc->sky[x + y * sc->sky_w];
@@ -893,6 +912,7 @@ void or_set_settings(or_scene *s, uint32_t spp, uint32_t max_ray_depth, float cl
     s->clamp_indirect = clamp_indirect; s->enable_multithreading = mt; s->enable_bvh_tree = bvh; s->mode = mode;
 }
 void or_set_trig_mode(or_scene *s, int m) { s->trig_mode = m; }
+void or_set_sky_filter(or_scene *s, int bilinear) { s->sky_bilinear = bilinear ? 1 : 0; }
 void or_set_background_uniform(or_scene *s, const float rgb[3]) { s->bg_kind = 0; s->bg_a = col_new(rgb[0], rgb[1], rgb[2]); }
 void or_set_background_gradient(or_scene *s, const float top[3], const float bottom[3]) {
     s->bg_kind = 1; s->bg_a = col_new(top[0], top[1], top[2]); s->bg_b = col_new(bottom[0], bottom[1], bottom[2]);

@@ -64,6 +64,9 @@ void or_set_camera(or_scene *s, const float lookfrom[3], const float lookat[3], 
 void or_set_settings(or_scene *s, uint32_t samples_per_pixel, uint32_t max_ray_depth, float clamp_indirect,
                      int enable_multithreading, int enable_bvh_tree, int mode);
 void or_set_trig_mode(or_scene *s, int trig_mode);
+/* 0 (default): SkyMap::sample's nearest texel (backgrounds.rs:84-92).  1: bilinear interpolation, an opt-in extension of the
+ * GPU library (option "sky_filter"), restated here only so that it can be checked */
+void or_set_sky_filter(or_scene *s, int bilinear);
 
 void or_set_background_uniform(or_scene *s, const float rgb[3]);                      /* backgrounds.rs:14-30 */
 void or_set_background_gradient(or_scene *s, const float top[3], const float bottom[3]); /* backgrounds.rs:32-49 */

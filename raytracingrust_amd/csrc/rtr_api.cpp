@@ -66,6 +66,7 @@ struct rtr_context {
     size_t wf_cap = 0;
     int sample_chunks = 0; // option "sample_chunks": 0 auto, else the number of pieces
     double chunk_timeout_s = 10.0; // option "chunk_timeout_ms": bound of a sample chunk's wait for its predecessor
+    bool sky_bilinear = false;     // option "sky_filter"
     bool debug_fault = false;      // option "debug_fault": the next launches set bit 1 of the fault word
     uint64_t debug_alloc_limit = 0; // option "debug_alloc_limit": scratch allocations above this many bytes fail (0: off)
     void *d_samples = nullptr; // k_render_bvh_sp: one float4 per (sample, pixel) of a launch
@@ -245,6 +246,7 @@ int launch_frame(rtr_context *ctx, const rtr_camera *camera, const rtr_settings 
     std::memcpy(p.bg_b, fs.bg_b, sizeof p.bg_b);
     p.sky = static_cast<const float *>(ctx->d_sky);
     p.sky_w = fs.sky_w; p.sky_h = fs.sky_h;
+    p.sky_bilinear = ctx->sky_bilinear ? 1u : 0u;
     p.tiles_x = (width + 7u) / 8u;
     uint32_t tiles_y = (height + 7u) / 8u;
     p.tiles_total = p.tiles_x * tiles_y;
@@ -616,6 +618,12 @@ int rtr_set_option(rtr_context *ctx, const char *name, const char *value) {
         const double ms = std::strtod(v.c_str(), &end);
         if (v.empty() || *end != '\0' || !(ms >= 0.0) || ms > 6.0e5) return fail(ctx, RTR_ERR_INVALID_ARGUMENT, "chunk_timeout_ms must be a number in [0, 600000]");
         ctx->chunk_timeout_s = ms * 1.0e-3;
+        return RTR_OK;
+    }
+    if (n == "sky_filter") { // takes effect at the next render
+        if (v == "nearest") ctx->sky_bilinear = false;
+        else if (v == "bilinear") ctx->sky_bilinear = true;
+        else return fail(ctx, RTR_ERR_INVALID_ARGUMENT, "sky_filter must be \"nearest\" or \"bilinear\"");
         return RTR_OK;
     }
     if (n == "debug_alloc_limit") { // testing aid: scratch buffers above this size cannot be allocated (0 = no limit)

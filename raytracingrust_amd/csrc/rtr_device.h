@@ -116,6 +116,7 @@ struct RenderParams {
     float bg_a[3], bg_b[3];
     const float *sky; // float4 texels
     uint32_t sky_w, sky_h;
+    uint32_t sky_bilinear; // option "sky_filter" = "bilinear": an extension, the reference takes the nearest texel
     // tile sharding
     uint32_t tiles_x, tiles_total, shard, n_shards;
     uint32_t tiles_launch;  // tiles this launch renders (shard, shard + n_shards, ...): grid = tiles_launch * chunks

@@ -936,6 +936,34 @@ RTR_DEV unsigned long long sky_texel_index(const RenderParams &p, V3 dir) {
     const unsigned long long x = xi, y = (unsigned long long)p.sky_h - 1ull - yi;
     return x + y * p.sky_w;
 }
+// Option "sky_filter" = "bilinear" (SURVEY.md section 8f N2): the four texels around the direction instead of the nearest
+// one -- longitude wraps, latitude clamps at the poles.  An extension, NOT what SkyMap::sample does; the oracle restates the
+// same arithmetic (or_set_sky_filter) so that it can be checked bit for bit.
+RTR_DEV V3 sky_bilinear(const RenderParams &p, V3 dir) {
+    V3 d = normalize(dir);
+    float sx = poly_acos(-d.y);
+    float sy = poly_atan2(-d.z, d.x) + kPi;
+    float u = sx / kPi;
+    float v = sy / (2.0f * kPi);
+    float fx = v * (float)p.sky_w - 0.5f, fy = u * (float)p.sky_h - 0.5f;
+    if (!(fx == fx)) fx = 0.0f;
+    if (!(fy == fy)) fy = 0.0f;
+    const float x0f = floorf(fx), r0f = floorf(fy);
+    const float tx = fx - x0f, ty = fy - r0f;
+    const long long w = (long long)p.sky_w, hh = (long long)p.sky_h;
+    long long x0 = (long long)x0f, r0 = (long long)r0f;
+    long long x1 = x0 + 1, r1 = r0 + 1;
+    x0 = ((x0 % w) + w) % w; x1 = ((x1 % w) + w) % w;
+    r0 = r0 < 0 ? 0 : (r0 > hh - 1 ? hh - 1 : r0); r1 = r1 < 0 ? 0 : (r1 > hh - 1 ? hh - 1 : r1);
+    const long long y0 = hh - 1 - r0, y1 = hh - 1 - r1;
+    const float4 *sky = reinterpret_cast<const float4 *>(p.sky);
+    const float4 t00 = sky[x0 + y0 * w], t01 = sky[x1 + y0 * w], t10 = sky[x0 + y1 * w], t11 = sky[x1 + y1 * w];
+    const float ux = 1.0f - tx, uy = 1.0f - ty;
+    const V3 a = add(scale(mk(t00.x, t00.y, t00.z), ux), scale(mk(t01.x, t01.y, t01.z), tx));
+    const V3 b = add(scale(mk(t10.x, t10.y, t10.z), ux), scale(mk(t11.x, t11.y, t11.z), tx));
+    return add(scale(a, uy), scale(b, ty));
+}
+
 // Background::sample (backgrounds.rs)
 RTR_DEV V3 background(const RenderParams &p, const Ray &r) {
     if (p.bg_kind == 0u) return ld3(p.bg_a); // backgrounds.rs:25-30
@@ -943,6 +971,7 @@ RTR_DEV V3 background(const RenderParams &p, const Ray &r) {
         float t = 0.5f * (normalize(r.d).y + 1.0f);
         return add(scale(ld3(p.bg_a), 1.0f - t), scale(ld3(p.bg_b), t));
     }
+    if (p.sky_bilinear) return sky_bilinear(p, r.d); // opt-in (option "sky_filter"), not reference behaviour
     // backgrounds.rs:84-92, math.rs:24-29: nearest texel of an equirectangular image
     const float4 texel = reinterpret_cast<const float4 *>(p.sky)[sky_texel_index(p, r.d)];
     return mk(texel.x, texel.y, texel.z);
@@ -1149,7 +1178,7 @@ RTR_DEV bool shade_segment(const RenderParams &p, bool was_hit, const Hit &h, Ra
     if (active) {
         if (!was_hit) {
             // defer_sky: the caller evaluates SkyMap::sample later, from the direction (k_render_bvh_sp -> k_sum_samples)
-            if (defer_sky && p.bg_kind == 2u) { *defer_sky = true; term = ray.d; }
+            if (defer_sky && p.bg_kind == 2u && !p.sky_bilinear) { *defer_sky = true; term = ray.d; }
             else term = background(p, ray);
             done = true;
         } else if (p.mode == 3u) { // RenderMode::Normal, render.rs:42-45

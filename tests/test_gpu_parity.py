@@ -814,3 +814,33 @@ def test_sample_buffers_shrink_when_the_device_is_short_of_memory():
             small.set_option("debug_alloc_limit", "1000")  # not even one sample fits: a clean error, not a crash
             with pytest.raises(rt.RtrError):
                 small.render(w + 8, h, seed=4)
+
+
+# ---- N2: opt-in bilinear SkyMap filter ---------------------------------------------------------------------------------
+@pytest.mark.parametrize("bvh", [True, False])
+def test_bilinear_sky_filter_matches_the_oracles_restatement(bvh):
+    """Option sky_filter = "bilinear" (SURVEY 8f N2) is an extension -- SkyMap::sample takes the nearest texel -- with its
+    arithmetic restated in the oracle: bit-exact for every tree kernel (the sample-parallel kernel's deferred sky lookup
+    stands down), different from the nearest-texel frame, and back to it when the option is reset."""
+    from raytracingrust_amd.hdri import synthetic_sky
+
+    scene = monkey_scene(3, material=rt.Dielectric(1.5), background=rt.SkyMap(synthetic_sky(96, 48, sun_radius=0.1)), bvh=bvh)
+    w, h = 96, 54
+    o_rgba, o_mean, o_st = pyoracle.OracleScene(scene, trig_mode=pyoracle.TRIG_POLY, sky_bilinear=True).render(w, h, 8, threads=0)
+    n_rgba, n_mean, _ = pyoracle.OracleScene(scene, trig_mode=pyoracle.TRIG_POLY).render(w, h, 8, threads=0)
+    assert not np.array_equal(o_mean, n_mean)
+    with rt.Renderer(0) as r:
+        r.upload_scene(scene)
+        r.set_option("sky_filter", "bilinear")
+        for kernel in (("auto", "wave", "samples", "stream") if bvh else ("auto",)):
+            r.set_option("tree_kernel", kernel)
+            rgba, mean = r.render(w, h, seed=8, want_rgba8=True, want_mean=True)
+            assert r.stats().segments == o_st.segments
+            c = compare(mean, rgba, o_mean, o_rgba)
+            assert c["mismatched_pixels"] == 0 and c["max_u8_delta"] == 0, (kernel, c)
+        r.set_option("sky_filter", "nearest")
+        r.set_option("tree_kernel", "auto")
+        rgba, mean = r.render(w, h, seed=8, want_rgba8=True, want_mean=True)
+        assert compare(mean, rgba, n_mean, n_rgba)["mismatched_pixels"] == 0
+        with pytest.raises(rt.RtrError):
+            r.set_option("sky_filter", "trilinear")

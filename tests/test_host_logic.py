@@ -269,7 +269,8 @@ def test_options_are_validated_without_a_device():
                                 ("samples_batch", ["3", "0"], "-1"),
                                 ("sample_chunks", ["1", "7", "auto"], "0"),
                                 ("chunk_timeout_ms", ["0", "2.5", "10000"], "-1"), ("debug_fault", ["on", "off"], "1"),
-                                ("debug_alloc_limit", ["4096", "0"], "lots")]:
+                                ("debug_alloc_limit", ["4096", "0"], "lots"),
+                                ("sky_filter", ["bilinear", "nearest"], "cubic")]:
             for v in good:
                 r.set_option(name, v)
             with pytest.raises(rt.RtrError):

@@ -379,3 +379,25 @@ def test_volume_over_a_mesh_boundary_known_answer():
         assert np.all(left == np.array([255, 180, 180], dtype=np.uint8)), np.unique(left, axis=0)
         assert np.all(right == np.array([0, 180, 180], dtype=np.uint8)), np.unique(right, axis=0)
         assert np.all(rgba[0, :, :3] == 0) and np.all(rgba[:, 0, :3] == 0)  # the corners see the background
+
+
+def test_bilinear_sky_filter_known_answers():
+    """The oracle's restatement of the opt-in bilinear SkyMap filter: on a constant image it is the nearest-texel frame
+    (the weights sum to one: a * (1 - t) + a * t == a only up to rounding, so compare within 2 ulp); on an image that is
+    linear in the column index it reproduces the column coordinate between texel centres."""
+    s = rt.Scene()
+    s.settings.samples_per_pixel = 1
+    s.camera = rt.Camera([0.0, 0.0, 0.0], [0.0, 0.0, -1.0], [0.0, 1.0, 0.0], 90.0, 1.0)
+    s.background = rt.SkyMap(np.full((8, 16, 3), 0.37, dtype=np.float32))
+    _, a, _ = pyoracle.OracleScene(s, sky_bilinear=True).render(32, 32, 3, threads=0)
+    _, b, _ = pyoracle.OracleScene(s).render(32, 32, 3, threads=0)
+    assert np.all(b == np.float32(0.37)) and np.max(np.abs(a - b)) <= 2 * np.spacing(np.float32(0.37))
+    ramp = np.zeros((4, 64, 3), dtype=np.float32)
+    ramp[:, :, 0] = (np.arange(64, dtype=np.float32) / np.float32(64.0))[None, :]  # (stays below clamp_indirect)
+    s.background = rt.SkyMap(ramp)
+    _, lin, _ = pyoracle.OracleScene(s, sky_bilinear=True).render(64, 8, 3, threads=0)
+    _, near, _ = pyoracle.OracleScene(s).render(64, 8, 3, threads=0)
+    red_l, red_n = lin[4, :, 0] * np.float32(64.0), near[4, :, 0] * np.float32(64.0)
+    assert np.all(red_n == np.floor(red_n))  # nearest: whole column indices
+    inner = (red_n > 1) & (red_n < 62)       # away from the longitude seam the interpolated value lies within half a texel
+    assert np.all(np.abs(red_l[inner] - red_n[inner]) <= 0.5 + 1e-4) and np.any(red_l[inner] != np.floor(red_l[inner]))
