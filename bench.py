@@ -201,8 +201,10 @@ def roofline_block(prof, prof_status, integrate_ms, alg_bytes, kernel_name):
         out["hbm_achieved_gbs"] = round(out["traffic"] / t / 1e9, 2)
         out["hbm_frac_measured"] = round(out["traffic"] / t / 1e9 / HBM_PEAK_GBS, 5)
     out["kernel_avg_ms_rocprof"] = round(float(prof.get("kernel_avg_ns_rocprof", 0.0)) / 1e6, 4)
-    out["vgprs_profiled"] = prof.get("vgpr")
-    out["sgprs_profiled"] = prof.get("sgpr")
+    out["vgprs_profiled"] = prof.get("compiled_vgprs", prof.get("vgpr"))
+    out["sgprs_profiled"] = prof.get("compiled_sgprs", prof.get("sgpr"))
+    out["sgpr_spills_profiled"] = prof.get("compiled_sgpr_spills")
+    out["vgpr_spills_profiled"] = prof.get("compiled_vgpr_spills")
     return out
 
 
@@ -239,12 +241,13 @@ def cpu_baseline(scene, width, height, spp_sample, seed):
 
 def other_configs(r, torch, dev, stream, seed):
     """Short secondary measurements, reported beside the headline so that the driver's record carries them too:
-    BASELINE's tree-world configurations (C1 simple.json, C3 monkey + HDRI, C4 house + plane + HDRI) at 1920x1080 and 256
-    spp, one warm-up frame and two timed frames each through the same device-resident entry point.  Flat scalars."""
+    BASELINE's tree-world configurations (C1 simple.json, C3 monkey + HDRI, C4 house + plane + HDRI at 1920x1080, C5
+    simple.json + HDRI at 3840x2160) at 256 spp, one warm-up frame and two timed frames each through the same
+    device-resident entry point.  Flat scalars."""
     from raytracingrust_amd.configs import baseline_config
 
     out = {}
-    for name in ("c1", "c3", "c4"):
+    for name in ("c1", "c3", "c4", "c5"):
         scene, W, H = baseline_config(name, 256)
         r.upload_scene(scene)
         rgba8 = torch.zeros((H, W, 4), dtype=torch.uint8, device=dev)
@@ -259,8 +262,9 @@ def other_configs(r, torch, dev, stream, seed):
         out[name + "_mrays_per_s"] = round(seg / dt / 1e6, 1)
         out[name + "_ms_per_frame"] = round(dt * 1e3, 3)
         out[name + "_segments_per_frame"] = int(seg)
-    out["note"] = ("1920x1080, 256 spp, reference (median-split) trees, tree_kernel auto; C1 simple.json 102 spheres, C3 monkey.obj + "
-                   "plane + synthetic HDRI, C4 house.obj + plane + synthetic HDRI depth 3; full lines: python bench.py --config cN")
+    out["note"] = ("256 spp, reference (median-split) trees, tree_kernel auto; 1920x1080: C1 simple.json 102 spheres, C3 monkey.obj + "
+                   "plane + synthetic HDRI, C4 house.obj + plane + synthetic HDRI depth 3; 3840x2160: C5 simple.json + HDRI (BASELINE "
+                   "quotes C3 at 512 and C5 at 1024 spp: 2x / 4x the frame time at the same rate); full lines: python bench.py --config cN")
     return out
 
 

@@ -112,6 +112,22 @@ if dominant:
         rec["active_lane_fraction"] = rec["sq_thread_cycles_valu"] / (rec["sq_active_inst_valu"] * 64.0)
     if rec["sq_insts_valu"]:
         rec["valu_issue_frac_at_rocprof_time"] = rec["sq_insts_valu"] / (rec["kernel_avg_ns_rocprof"] * 1e-9) / (256 * 4 * 2.4e9 / 2)
+    # what the compiler allocated for the dominant kernel (rocprofv3's VGPR_Count is in allocation granules)
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "scripts"))
+        import kernel_resources
+
+        short = dominant.replace("void ", "").split("(")[0]
+        for k in kernel_resources.resources():
+            if k["name"].split("(")[0] == short:
+                rec["compiled_vgprs"] = int(k.get("VGPRs", 0))
+                rec["compiled_sgprs"] = int(k.get("TotalSGPRs", 0))
+                rec["compiled_vgpr_spills"] = int(k.get("VGPRs Spill", 0))
+                rec["compiled_sgpr_spills"] = int(k.get("SGPRs Spill", 0))
+                rec["compiled_scratch_bytes_per_lane"] = int(k.get("ScratchSize [bytes/lane]", 0))
+                rec["compiled_occupancy_waves_per_simd"] = int(k.get("Occupancy [waves/SIMD]", 0))
+    except Exception as exc:  # the profile stands without it
+        rec["compiled_resources_error"] = str(exc)
     path = os.path.join(out, rec["workload"] + ".json")
     with open(path, "w") as fh:
         json.dump(rec, fh, indent=1)
