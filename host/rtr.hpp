@@ -18,6 +18,7 @@
 // Errors: the reference panics; here they are std::runtime_error carrying the library's message.
 #pragma once
 
+#include <algorithm>
 #include <charconv>
 #include <cmath>
 #include <cstdint>
@@ -505,6 +506,67 @@ struct RenderTarget {
     std::vector<uint8_t> data;
     bool request_redraw = false;
     RenderTarget(size_t w, size_t h) : width(w), height(h), data(w * h * 4, 0) {}
+
+    // Image files of the RGBA8 buffer (the reference only shows it in its egui window,
+    // src/gui.rs).  ".png": 8-bit RGBA, deflate "stored" blocks (no zlib dependency); anything else: binary PPM (P6, rgb).
+    void save(const std::string &path) const {
+        FILE *f = std::fopen(path.c_str(), "wb");
+        if (!f) throw std::runtime_error("cannot write " + path);
+        const bool png = path.size() >= 4 && path.compare(path.size() - 4, 4, ".png") == 0;
+        if (!png) {
+            std::fprintf(f, "P6\n%zu %zu\n255\n", width, height);
+            for (size_t i = 0; i < width * height; i++) std::fwrite(&data[4 * i], 1, 3, f);
+            std::fclose(f);
+            return;
+        }
+        uint32_t crc_table[256];
+        for (uint32_t n = 0; n < 256; n++) {
+            uint32_t c = n;
+            for (int k = 0; k < 8; k++) c = (c & 1u) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
+            crc_table[n] = c;
+        }
+        auto be32 = [](std::vector<uint8_t> &v, uint32_t x) { for (int k = 3; k >= 0; k--) v.push_back((uint8_t)(x >> (8 * k))); };
+        auto chunk = [&](const char *type, const std::vector<uint8_t> &body) {
+            std::vector<uint8_t> c;
+            be32(c, (uint32_t)body.size());
+            c.insert(c.end(), type, type + 4);
+            c.insert(c.end(), body.begin(), body.end());
+            uint32_t crc = 0xFFFFFFFFu;
+            for (size_t i = 4; i < c.size(); i++) crc = crc_table[(crc ^ c[i]) & 0xFFu] ^ (crc >> 8);
+            be32(c, crc ^ 0xFFFFFFFFu);
+            std::fwrite(c.data(), 1, c.size(), f);
+        };
+        static const uint8_t magic[8] = {0x89, 'P', 'N', 'G', '\r', '\n', 0x1A, '\n'};
+        std::fwrite(magic, 1, 8, f);
+        std::vector<uint8_t> ihdr;
+        be32(ihdr, (uint32_t)width);
+        be32(ihdr, (uint32_t)height);
+        const uint8_t tail[5] = {8, 6, 0, 0, 0}; // bit depth 8, colour type 6 (RGBA), deflate, filter 0, no interlace
+        ihdr.insert(ihdr.end(), tail, tail + 5);
+        chunk("IHDR", ihdr);
+        std::vector<uint8_t> raw; // scanlines, each led by filter type 0
+        raw.reserve(height * (width * 4 + 1));
+        for (size_t y = 0; y < height; y++) {
+            raw.push_back(0);
+            raw.insert(raw.end(), data.begin() + 4 * width * y, data.begin() + 4 * width * (y + 1));
+        }
+        std::vector<uint8_t> z = {0x78, 0x01};
+        uint32_t a = 1u, b = 0u; // Adler-32 of the raw stream
+        size_t pos = 0;
+        do {
+            const size_t len = std::min<size_t>(65535, raw.size() - pos);
+            z.push_back(pos + len == raw.size() ? 1 : 0);
+            z.push_back((uint8_t)(len & 0xFF)); z.push_back((uint8_t)(len >> 8));
+            z.push_back((uint8_t)(~len & 0xFF)); z.push_back((uint8_t)((~len >> 8) & 0xFF));
+            for (size_t i = 0; i < len; i++) { a = (a + raw[pos + i]) % 65521u; b = (b + a) % 65521u; }
+            z.insert(z.end(), raw.begin() + pos, raw.begin() + pos + len);
+            pos += len;
+        } while (pos < raw.size());
+        be32(z, (b << 16) | a);
+        chunk("IDAT", z);
+        chunk("IEND", {});
+        std::fclose(f);
+    }
 };
 
 // One rtr_context: amortises the scene upload over many frames.  device = -1: host-only (lowering + BVH only).

@@ -99,13 +99,7 @@ int main(int argc, char **argv) {
         std::printf("rendered %zux%zu spp %u: %.3f ms (kernel %.3f ms), %llu ray segments, %.1f Mrays/s\n", width, height,
                     scene.settings.samples_per_pixel, ms, st.kernel_ms, (unsigned long long)st.segments,
                     st.kernel_ms > 0 ? st.segments / st.kernel_ms / 1e3 : 0.0);
-        if (!out.empty()) {
-            FILE *f = std::fopen(out.c_str(), "wb");
-            if (!f) throw std::runtime_error("cannot write " + out);
-            std::fprintf(f, "P6\n%zu %zu\n255\n", width, height);
-            for (size_t i = 0; i < width * height; i++) std::fwrite(&target.data[4 * i], 1, 3, f);
-            std::fclose(f);
-        }
+        if (!out.empty()) target.save(out); // .png or .ppm
         if (!f32_out.empty()) {
             std::vector<float> mean;
             r.render_f32(scene, width, height, seed, mean);

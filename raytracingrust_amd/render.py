@@ -31,6 +31,29 @@ class RenderTarget:
     def image(self) -> np.ndarray:
         return self.data.reshape(self.height, self.width, 4)
 
+    def save(self, path: str) -> None:
+        """Writes the RGBA8 buffer as an image file (the reference only shows it in its egui
+        window, src/gui.rs): ``.png`` -> 8-bit RGBA PNG, anything else -> binary PPM (P6, rgb)."""
+        img = self.image()
+        if not path.lower().endswith(".png"):
+            with open(path, "wb") as f:
+                f.write(b"P6\n%d %d\n255\n" % (self.width, self.height))
+                f.write(np.ascontiguousarray(img[:, :, :3]).tobytes())
+            return
+        import struct
+        import zlib
+
+        def chunk(kind: bytes, body: bytes) -> bytes:
+            return struct.pack(">I", len(body)) + kind + body + struct.pack(">I", zlib.crc32(kind + body) & 0xFFFFFFFF)
+
+        raw = np.zeros((self.height, 1 + 4 * self.width), dtype=np.uint8)  # each scanline led by filter type 0
+        raw[:, 1:] = img.reshape(self.height, 4 * self.width)
+        with open(path, "wb") as f:
+            f.write(b"\x89PNG\r\n\x1a\n")
+            f.write(chunk(b"IHDR", struct.pack(">IIBBBBB", self.width, self.height, 8, 6, 0, 0, 0)))
+            f.write(chunk(b"IDAT", zlib.compress(raw.tobytes(), 6)))
+            f.write(chunk(b"IEND", b""))
+
 
 class SceneInfo:
     def __init__(self, s: _capi.rtr_scene_info):

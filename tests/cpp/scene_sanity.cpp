@@ -120,6 +120,12 @@ int main(int argc, char **argv) {
         s.background = std::move(sky);
         check_scene(s, "pfm sky");
     }
+    if (argc > 3) { // image writers: a 70000-byte raw stream spans two stored deflate blocks; decoded by the Python side
+        RenderTarget t(250, 70);
+        for (size_t i = 0; i < t.data.size(); i++) t.data[i] = (uint8_t)((i * 7u + i / 1000u) & 0xFFu);
+        t.save(std::string(argv[3]) + "/sanity.png");
+        t.save(std::string(argv[3]) + "/sanity.ppm");
+    }
     std::printf("%s\n", fails ? "FAILED" : "ok");
     return fails != 0;
 }

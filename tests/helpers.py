@@ -30,3 +30,35 @@ def compare(gpu_mean, gpu_rgba, o_mean, o_rgba):
     neq = np.any(bits(gpu_mean) != bits(o_mean), axis=-1)
     du8 = int(np.max(np.abs(gpu_rgba.astype(np.int32) - o_rgba.astype(np.int32)))) if gpu_rgba is not None else 0
     return {"rel_l2": rel, "mismatched_pixels": int(np.count_nonzero(neq)), "max_u8_delta": du8}
+
+
+def read_png(path):
+    """Minimal decoder for the PNGs RenderTarget.save writes (8-bit RGBA, filter type 0 only, no interlace)."""
+    import struct
+    import zlib
+
+    data = open(path, "rb").read()
+    assert data[:8] == b"\x89PNG\r\n\x1a\n"
+    pos, idat, w = 8, b"", None
+    while pos < len(data):
+        n, kind = struct.unpack(">I4s", data[pos:pos + 8])
+        body = data[pos + 8:pos + 8 + n]
+        (crc,) = struct.unpack(">I", data[pos + 8 + n:pos + 12 + n])
+        assert crc == zlib.crc32(kind + body) & 0xFFFFFFFF, kind
+        if kind == b"IHDR":
+            w, h, depth, colour, comp, filt, lace = struct.unpack(">IIBBBBB", body)
+            assert (depth, colour, comp, filt, lace) == (8, 6, 0, 0, 0)
+        elif kind == b"IDAT":
+            idat += body
+        pos += 12 + n
+    raw = np.frombuffer(zlib.decompress(idat), dtype=np.uint8).reshape(h, 1 + 4 * w)
+    assert not raw[:, 0].any()
+    return raw[:, 1:].reshape(h, w, 4).copy()
+
+
+def read_ppm(path):
+    data = open(path, "rb").read()
+    magic, dims, maxv, rest = data.split(b"\n", 3)
+    assert magic == b"P6" and maxv == b"255"
+    w, h = map(int, dims.split())
+    return np.frombuffer(rest, dtype=np.uint8).reshape(h, w, 3).copy()

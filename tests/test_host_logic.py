@@ -288,3 +288,14 @@ def test_options_are_validated_without_a_device():
         off = r.scene_info()
         assert (off.n_nodes, off.n_leaves, off.tree_height) == (base.n_nodes, base.n_leaves, base.tree_height)
         assert off.device_bytes >= base.device_bytes  # unfolded pairs are node records again
+
+
+def test_render_target_writes_png_and_ppm(tmp_path):
+    from helpers import read_png, read_ppm
+
+    t = rt.RenderTarget(37, 11)
+    t.data[:] = (np.arange(t.data.size) * 13 % 251).astype(np.uint8)
+    t.save(str(tmp_path / "a.png"))
+    t.save(str(tmp_path / "a.ppm"))
+    np.testing.assert_array_equal(read_png(str(tmp_path / "a.png")), t.image())
+    np.testing.assert_array_equal(read_ppm(str(tmp_path / "a.ppm")), t.image()[:, :, :3])

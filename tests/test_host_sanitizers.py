@@ -32,6 +32,12 @@ def test_scene_builder_under_asan_and_ubsan(tmp_path):
     r = subprocess.run([exe, os.path.join(ROOT, "data"), pfm, str(tmp_path)], capture_output=True, text=True,
                        env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1", UBSAN_OPTIONS="print_stacktrace=1"))
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.stdout[-2000:], r.stderr[-3000:])
+    # the image files the driver wrote decode to the pattern it filled in
+    from helpers import read_png, read_ppm
+
+    want = ((np.arange(250 * 70 * 4, dtype=np.uint64) * 7 + np.arange(250 * 70 * 4, dtype=np.uint64) // 1000) & 0xFF).astype(np.uint8).reshape(70, 250, 4)
+    np.testing.assert_array_equal(read_png(str(tmp_path / "sanity.png")), want)
+    np.testing.assert_array_equal(read_ppm(str(tmp_path / "sanity.ppm")), want[:, :, :3])
     # the C++ writer's document for benchmark.json (printed by the driver) equals the Python writer's
     import json
 
