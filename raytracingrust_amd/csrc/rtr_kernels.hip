@@ -519,6 +519,11 @@ RTR_DEV void test_leaf(const RenderParams &p, uint32_t ref, const Ray &r, V3 inv
     }
 }
 
+// A per-lane condition as the wave's 64-bit lane mask (a scalar register pair: what the compare wrote) and back.
+__device__ __forceinline__ uint64_t wave_mask(bool c) { return __builtin_amdgcn_ballot_w64(c); }
+__device__ __forceinline__ bool lane_of(uint64_t mask) { return __builtin_amdgcn_inverse_ballot_w64(mask); }
+
+
 // One trip of BvhNode::hit (bvh.rs:146-172) over the flattened tree for a lane whose walk is in progress: a node step (both
 // children's boxes from one 64-byte record) unless the lane stands at a leaf, then a leaf test if it stands at one now (the
 // second leaf of a collapsed pair follows in the next trip, no stack traffic), then, when the lane has nowhere to descend,
@@ -573,8 +578,11 @@ RTR_DEV void test_leaf(const RenderParams &p, uint32_t ref, const Ray &r, V3 inv
                 const bool gr_ = (r_ & (REF_LEAF | REF_PAIR)) != REF_LEAF;                                               \
                 el_ = gl_ ? tl_ : 0.0f;                                                                                  \
                 er_ = gr_ ? tr_ : 0.0f;                                                                                  \
-                hl_ = hl_ && (!gl_ || (sl_ && (lvol_ || !(tl_ > best.cull)))); /* cull is +inf until a leaf is hit */    \
-                hr_ = hr_ && (!gr_ || (sr_ && (rvol_ || !(tr_ > best.cull))));                                           \
+                /* hl = nonempty && (!boxed || (slab && (vol || !(t > cull)))), cull being +inf until a leaf is hit --   */ \
+                /* combined as wave masks in scalar registers: written on bools the compiler turns the expression into   */ \
+                /* selects of 0/1 vectors (five vector instructions per child, ten per node step).                       */ \
+                hl_ = lane_of(wave_mask(hl_) & (~wave_mask(gl_) | (wave_mask(sl_) & (wave_mask(lvol_) | ~wave_mask(tl_ > best.cull))))); \
+                hr_ = lane_of(wave_mask(hr_) & (~wave_mask(gr_) | (wave_mask(sr_) & (wave_mask(rvol_) | ~wave_mask(tr_ > best.cull))))); \
             } else {                                                                                                     \
                 if (hl_ && (l_ & (REF_LEAF | REF_PAIR)) != REF_LEAF) {                                                   \
                     hl_ = slab(lmin_, lmax_, RAY, inv, TMAX_BOX, el_);                                                   \
