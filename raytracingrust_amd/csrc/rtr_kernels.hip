@@ -1764,11 +1764,13 @@ __global__ __launch_bounds__(64, RTR_X_BVH_WAVES) void k_render_bvh(const Render
 // counter as they finish; each sample's clamped radiance is written to p.samples[sample][pixel], and k_sum_samples adds
 // a pixel's samples in index order afterwards (the same additions as calculate_pixel's loop).  No lane waits for its
 // tile's slowest pixel, and sample ranges need no hand-over between workgroups.
-// 6 waves per SIMD and 128 SGPRs: 80 VGPRs without the spills the 7-wave budget forces on this kernel (+4 ... 5 %)
+// Register budget: 7 waves per SIMD (72 VGPRs) for scenes without volumes -- with the lane states in scalar masks the
+// kernel needs 77, and the 7-wave build spills at most two (C1 +2.5 %, C3 +4 %, C4 -0.5 %: house.obj's 6 KB of stack
+// per wave allow 27 waves per CU either way); 6 waves for the volume kernels, which would spill 8 ... 25.
 template <uint32_t VOL, bool MESH>
 __attribute__((amdgpu_num_sgpr(128)))
 #ifndef RTR_X_SP_WAVES
-#define RTR_X_SP_WAVES 6
+#define RTR_X_SP_WAVES (VOL == 0u ? 7 : 6)
 #endif
 __global__ __launch_bounds__(64, RTR_X_SP_WAVES) void k_render_bvh_sp(const RenderParams p) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
@@ -1832,8 +1834,11 @@ __global__ __launch_bounds__(64, RTR_X_SP_WAVES) void k_render_bvh_sp(const Rend
     best_reset(best);
     V3 inv = mk(0.0f, 0.0f, 0.0f);
     float a = 0.0f;
-    bool walking = false;
-    auto begin_segment = [&]() { // the head of world_hit<WORLD_BVH>
+    // Lane states are wave masks in scalar registers (walking_m, alive_m, need_m), changed only where the wave is
+    // converged: as per-lane bools carried round the loops they live in vector registers as bytes, re-tested and copied
+    // on every trip.
+    uint64_t walking_m = 0ull;
+    auto begin_segment = [&]() -> bool { // the head of world_hit<WORLD_BVH>; true = the lane has a walk to take
         nseg++;
         a = dot(ray.d, ray.d);
         inv = mk(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z);
@@ -1845,57 +1850,64 @@ __global__ __launch_bounds__(64, RTR_X_SP_WAVES) void k_render_bvh_sp(const Rend
             go = slab(p.root_box, p.root_box + 3, ray, inv, __builtin_inff(), e);
         }
         cur = root; sp = 0;
-        walking = go;
+        return go;
     };
-    bool alive = false;
-    bool need = true; // the lane wants the workgroup's next (sample, pixel) pair
+    uint64_t alive_m = 0ull;
+    uint64_t need_m = wave_mask(true); // the lanes that want the workgroup's next (sample, pixel) pair
     const uint64_t n_pixels = (uint64_t)p.width * p.height;
     auto fetch_work = [&]() { // hand the next items to the lanes that ask, in lane order; wave-uniform control flow
-        while (__ballot(need) != 0ull) {
-            const uint64_t asking = __ballot(need);
+        bool began = false;
+        while (need_m != 0ull) {
+            const uint64_t asking = need_m;
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(asking >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)asking, 0u));
             const uint32_t item = next_item + rank;
             next_item += (uint32_t)__popcll(asking);
-            if (need) {
-                if (item >= n_items) {
-                    need = false; // nothing left: the lane retires
-                } else {
+            bool again = false, got = false;
+            if (lane_of(asking)) {
+                if (item < n_items) { // else nothing is left: the lane retires
                     const uint32_t pix = item & 63u, si = s_first + (item >> 6);
                     const uint32_t x = tx * 8u + (pix & 7u), y = ty * 8u + (pix >> 3);
-                    if (x < p.width && y < p.height) { // else: off the ragged edge, ask again
+                    if (x < p.width && y < p.height) {
                         const uint32_t pixel = y * p.width + x; // render.rs:76-77
                         fx = (float)x; fy = (float)y;
                         hp = hash32(pixel ^ p.seed_key0);
                         rng.inc = (hash32(hp + p.seed_key1) << 1) | 1u;
                         slot = (uint64_t)(si - p.sample_begin) * n_pixels + pixel;
-                        need = false;
-                        alive = true;
+                        got = true;
                         start_sample(si);
-                        begin_segment();
+                        began = begin_segment();
+                    } else {
+                        again = true; // off the ragged edge: ask again
                     }
                 }
             }
+            need_m = wave_mask(again);
+            alive_m |= wave_mask(got);
         }
+        walking_m |= wave_mask(began);
     };
     fetch_work();
 
     for (;;) {
-        const uint64_t alive_mask = __ballot(alive);
-        if (alive_mask == 0ull) break;
-        const uint32_t quorum = (uint32_t)__popcll(alive_mask) * RTR_TREE_QUORUM_NUM / RTR_TREE_QUORUM_DEN;
-        RTR_LS1(0) RTR_LS(15, alive)
+        if (alive_m == 0ull) break;
+        const uint32_t quorum = (uint32_t)__popcll(alive_m) * RTR_TREE_QUORUM_NUM / RTR_TREE_QUORUM_DEN;
+        RTR_LS1(0) RTR_LS(15, lane_of(alive_m))
         // ---- walk: one trip per iteration for every lane still walking ----
         // (RTR_WALK_TRIP: the one trip body every walk expands in place.)
-        while ((uint32_t)__popcll(__ballot(walking)) > quorum) {
+        while ((uint32_t)__popcll(walking_m) > quorum) {
             // (Taking only the kind of step -- node or leaf -- that more walkers wait for was measured 0 ... -10 %:
             // with both bodies in one trip their gathers overlap.)
             // kWalkUnroll trips per quorum check: C3 +15 %, C4 +5 % over one (2, 3, 4, 6, 8 measured: flat from 3 on)
 #pragma unroll
-            for (uint32_t rep = 0; rep < kWalkUnroll; rep++)
-            if (walking) RTR_WALK_TRIP(ray, __builtin_inff(), walking = false)
+            for (uint32_t rep = 0; rep < kWalkUnroll; rep++) {
+                bool ended = false;
+                if (lane_of(walking_m)) RTR_WALK_TRIP(ray, __builtin_inff(), ended = true)
+                walking_m &= ~wave_mask(ended);
+            }
         }
         // ---- the lanes whose walk has ended: the rest of trace_ray, then the next segment or the next sample ----
-        if (alive && !walking) {
+        bool began = false, finished = false;
+        if (lane_of(alive_m & ~walking_m)) {
             RTR_LS1(11) RTR_LS(12, true)
             Hit h;
             const bool was_hit = best.leaf != REF_NONE;
@@ -1924,12 +1936,14 @@ __global__ __launch_bounds__(64, RTR_X_SP_WAVES) void k_render_bvh_sp(const Rend
                     const V3 rad = sample_radiance(p, lds_mats, chain, term);
                     reinterpret_cast<float4 *>(p.samples)[slot] = make_float4(rad.x, rad.y, rad.z, 0.0f);
                 }
-                alive = false;
-                need = true;
+                finished = true;
             } else {
-                begin_segment();
+                began = begin_segment();
             }
         }
+        walking_m |= wave_mask(began);
+        need_m = wave_mask(finished);
+        alive_m &= ~need_m;
         fetch_work();
     }
 
