@@ -426,6 +426,14 @@ RTR_DEV bool mesh_range_hit(const DevNode *nodes, const DevLeafHot *leaf_hot, ui
 RTR_DEV void gather_fence(const float4 &a, const float4 &b, const float4 &c) {
     asm volatile("" ::"v"(a.x), "v"(a.y), "v"(a.z), "v"(a.w), "v"(b.x), "v"(b.y), "v"(b.z), "v"(b.w), "v"(c.x), "v"(c.y), "v"(c.z), "v"(c.w));
 }
+RTR_DEV void gather_fence(const float4 &a, const float4 &b, const float4 &c, const float2 &d) {
+    asm volatile("" ::"v"(a.x), "v"(a.y), "v"(a.z), "v"(a.w), "v"(b.x), "v"(b.y), "v"(b.z), "v"(b.w), "v"(c.x), "v"(c.y), "v"(c.z), "v"(c.w),
+                 "v"(d.x), "v"(d.y));
+}
+RTR_DEV void gather_fence(const float4 &a, const float4 &b, float c) {
+    asm volatile("" ::"v"(a.x), "v"(a.y), "v"(a.z), "v"(a.w), "v"(b.x), "v"(b.y), "v"(b.z), "v"(b.w), "v"(c));
+}
+RTR_DEV void gather_fence(const float4 &a, float b) { asm volatile("" ::"v"(a.x), "v"(a.y), "v"(a.z), "v"(a.w), "v"(b)); }
 RTR_DEV void gather_fence(const float4 &a, const float4 &b, const float4 &c, const float4 &d) {
     asm volatile("" ::"v"(a.x), "v"(a.y), "v"(a.z), "v"(a.w), "v"(b.x), "v"(b.y), "v"(b.z), "v"(b.w), "v"(c.x), "v"(c.y), "v"(c.z), "v"(c.w),
                  "v"(d.x), "v"(d.y), "v"(d.z), "v"(d.w));
@@ -492,28 +500,35 @@ template <uint32_t VOL>
 RTR_DEV void test_leaf(const RenderParams &p, uint32_t ref, const Ray &r, V3 inv, float a, Best &best, Rng &rng, uint32_t *stk_ref,
                        uint32_t sp, uint32_t lane) {
     (void)inv; (void)stk_ref; (void)sp; (void)lane;
+    // A wave's gather of per-lane records costs the vector L1 ~43 clocks for every 16-byte load instruction and next to
+    // nothing for an 8- or 4-byte one (scripts/ubench/gather.hip: 48 B as 3 x 16 -> 71 ns per wave-gather and CU, 36 B as
+    // 16 + 16 + 4 -> 54 ns), and the tree kernels are bound by exactly that: each kind of leaf loads what it reads.
     const float4 *hot = reinterpret_cast<const float4 *>(p.leaf_hot + (ref & REF_INDEX));
-    float4 q0 = hot[0], q1 = hot[1], q2 = hot[2];
-#ifndef RTR_X_NO_GATHER_FENCE
-    gather_fence(q0, q1, q2);
-#endif
     if (ref & REF_TRI) {
+        const float4 q0 = hot[0], q1 = hot[1];
+        const float q2x = reinterpret_cast<const float *>(hot)[8];
+        gather_fence(q0, q1, q2x);
         float t, u, v;
         // (Möller-Trumbore without its early exits -- all four tests on every lane -- was measured neutral.)
-        if (triangle_t(mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y), mk(q1.z, q1.w, q2.x), r, t, u, v) &&
+        if (triangle_t(mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y), mk(q1.z, q1.w, q2x), r, t, u, v) &&
             accept_tree(best, t, ref)) {
             best_take(best, t, u, v, ref);
         }
     } else if (VOL && (ref & REF_VOL)) {
+        const float4 q0 = hot[0], q1 = hot[1], q2 = hot[2];
+        gather_fence(q0, q1, q2);
         float t;
         // Volume::hit(ray, tmin, +inf) as called from the tree (bvh.rs:156)
         if (volume_leaf_t<VOL>(p, q0, q1, q2, r, inv, a, __builtin_inff(), rng, stk_ref, sp, lane, t) && accept_tree(best, t, ref)) {
             best_take(best, t, best.u, best.v, ref);
         }
     } else {
+        const float4 q0 = hot[0]; // centre, radius
+        const float r2 = reinterpret_cast<const float *>(hot)[4];
+        gather_fence(q0, r2);
         float t;
         // Sphere::hit(ray, tmin, +inf) as called from the tree (bvh.rs:156)
-        if (sphere_t(mk(q0.x, q0.y, q0.z), q1.x, r, a, __builtin_inff(), t) && accept_tree(best, t, ref)) {
+        if (sphere_t(mk(q0.x, q0.y, q0.z), r2, r, a, __builtin_inff(), t) && accept_tree(best, t, ref)) {
             best_take(best, t, best.u, best.v, ref);
         }
     }
@@ -558,8 +573,17 @@ __device__ __forceinline__ bool lane_of(uint64_t mask) { return __builtin_amdgcn
         if (!leaf0_) {                                                                                                   \
             RTR_LS1(6) RTR_LS(5, true)                                                                                   \
             const float4 *nq_ = reinterpret_cast<const float4 *>(p.nodes + cur);                                         \
-            float4 q0_ = nq_[0], q1_ = nq_[1], q2_ = nq_[2], q3_ = nq_[3];                                               \
-            gather_fence(q0_, q1_, q2_, q3_);                                                                            \
+            /* the two refs are an 8-byte load unless the flags word is needed: a fourth 16-byte load costs the vector */ \
+            /* L1 a fifth of the node gather's time, an 8-byte one nothing (see test_leaf)                             */ \
+            float4 q0_ = nq_[0], q1_ = nq_[1], q2_ = nq_[2], q3_;                                                        \
+            if constexpr (VOL != 0u) {                                                                                   \
+                q3_ = nq_[3];                                                                                            \
+                gather_fence(q0_, q1_, q2_, q3_);                                                                        \
+            } else {                                                                                                     \
+                const float2 refs_ = *reinterpret_cast<const float2 *>(nq_ + 3);                                         \
+                gather_fence(q0_, q1_, q2_, refs_);                                                                      \
+                q3_ = make_float4(refs_.x, refs_.y, 0.0f, 0.0f);                                                         \
+            }                                                                                                            \
             float lmin_[3] = {q0_.x, q0_.y, q0_.z}, lmax_[3] = {q0_.w, q1_.x, q1_.y};                                    \
             float rmin_[3] = {q1_.z, q1_.w, q2_.x}, rmax_[3] = {q2_.y, q2_.z, q2_.w};                                    \
             const uint32_t l_ = __float_as_uint(q3_.x), r_ = __float_as_uint(q3_.y);                                     \
