@@ -210,7 +210,10 @@ int launch_frame(rtr_context *ctx, const rtr_camera *camera, const rtr_settings 
     p.clamp_indirect = st->clamp_indirect;
     seed_keys(seed, p.seed_key0, p.seed_key1);
     // render.rs:68-72: the tree when enable_bvh_tree, else the linear scan of scene.rs:141-157
-    if (st->enable_bvh_tree) { p.world = rtr::WORLD_BVH; p.stack_cap = fs.stack_depth + 1u; }
+    // stack entries: a walk pushes at most once per node record on its path (FlatScene::stack_depth, checked by
+    // tests/cpp/scene_sanity.cpp); one more where a Volume's nested mesh walk starts above the outer walk's entries.
+    // Exact, because LDS per wave bounds the tree kernels' occupancy: house.obj 6016 -> 5632 B = 27 -> 28 waves per CU.
+    if (st->enable_bvh_tree) { p.world = rtr::WORLD_BVH; p.stack_cap = std::max(1u, fs.stack_depth + (fs.has_volumes ? 1u : 0u)); }
     else if (fs.spheres_only) { p.world = rtr::WORLD_LINEAR_SPHERES; p.stack_cap = 0u; }
     else { p.world = rtr::WORLD_LINEAR_GENERIC; p.stack_cap = fs.mesh_stack_depth + 1u; }
     p.n_objects = fs.n_objects;
