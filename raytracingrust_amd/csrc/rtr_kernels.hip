@@ -475,9 +475,14 @@ RTR_DEV void best_take(Best &b, float t, float u, float v, uint32_t leaf) {
 }
 
 // Candidate acceptance inside one tree: the reference merges with `left < right ? left : right`
-// (bvh.rs:181-186): the smaller t wins and the later leaf in depth-first order wins exact ties.
+// (bvh.rs:181-186): the smaller t wins, and the right operand -- the later leaf in depth-first order -- wins whenever
+// the left one is not strictly smaller: exact ties, and any comparison with a NaN distance (a sphere hit by a ray with
+// non-finite components: `disc = NaN` slips through objects.rs:31).  Pairwise this is exactly the merge; over a whole
+// tree it equals the reference's nested merges when the hits are all finite or all NaN (a NaN ray makes every sphere's
+// distance NaN, and the last hit leaf wins as in the reference); a MIX of NaN and finite distances on one ray is not
+// an order, the nested merges then depend on the tree's shape, and that case alone stays a documented deviation.
 RTR_DEV bool accept_tree(const Best &b, float t, uint32_t leaf) {
-    return b.leaf == REF_NONE || t < b.t || (t == b.t && (leaf & REF_INDEX) > (b.leaf & REF_INDEX));
+    return b.leaf == REF_NONE || t < b.t || (!(b.t < t) && (leaf & REF_INDEX) > (b.leaf & REF_INDEX));
 }
 
 // Volume::hit for the Volume leaf record q0..q2 (rtr_device.h): sphere boundary, or a mesh boundary walked on the lane's

@@ -277,11 +277,14 @@ def test_volume_over_a_mesh_boundary(gpu_renderer, bvh, sphere_fog):
     assert c["max_u8_delta"] == 0
 
 
+@pytest.mark.parametrize("tree", ["linear", "bvh", "simple"])
 @pytest.mark.parametrize("w,h", [(1, 1), (1, 9), (9, 1), (2, 2), (8, 8), (9, 9)])
-def test_degenerate_target_sizes(gpu_renderer, w, h):
+def test_degenerate_target_sizes(gpu_renderer, w, h, tree):
     """render.rs:88-89 divides by (W-1) and (H-1): a 1-pixel-wide target makes u or v inf/NaN.  The reference does
-    not guard it; neither do we -- but the GPU must go wrong exactly like the oracle (NaN where it has NaN)."""
-    scene = benchmark_scene(3)
+    not guard it; neither do we -- but the GPU must go wrong exactly like the oracle (NaN where it has NaN).
+    In the tree worlds every sphere then reports a NaN distance and the nested merges (bvh.rs:181-198, NaN -> right) pick
+    the last hit leaf: an Emission sphere there returns a finite colour, so the choice is visible."""
+    scene = simple_scene(3) if tree == "simple" else benchmark_scene(3, enable_bvh_tree=(tree == "bvh"))
     r = gpu_renderer
     r.upload_scene(scene)
     rgba, mean = r.render(w, h, seed=13, want_rgba8=True, want_mean=True)
