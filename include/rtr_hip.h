@@ -243,6 +243,12 @@ int rtr_abi_version(void);
  *   "sky_filter" = "nearest" (default: SkyMap::sample, backgrounds.rs:84-92) | "bilinear": interpolate the four texels
  *                 around the direction (longitude wraps, latitude clamps).  An extension, not reference behaviour.
  *   "debug_fault" = "off" (default) | "on": testing aid; launches set the fault word themselves.
+ *   "stack_entries" = "auto" (default) | "wide": the samples kernel keeps a traversal-stack entry in one 32-bit word (4 flag
+ *               bits, 16-bit index, 12 bits of entry distance) for trees of at most 65 536 nodes and leaves, else in a
+ *               32-bit ref plus a 16-bit distance; "wide" forces the second form (tests).  The distance is a lower bound used
+ *               only to skip boxes the best hit has overtaken: the frame does not depend on the form, the LDS footprint
+ *               (and with it the occupancy: LDS is granted in 1280-byte steps) does.
+ *   "debug_lds_pad" = "0" (default) | bytes up to 65536: measuring aid, extra dynamic LDS per workgroup.
  *   "debug_alloc_limit" = "0" (default: none) | bytes: testing aid; scratch allocations above that size fail as if the
  *                 device were out of memory (exercises the batch-halving retry of the "samples" / "stream" kernels).
  * A scratch buffer that has to grow is freed and reallocated inside the call that needs it, which synchronises the

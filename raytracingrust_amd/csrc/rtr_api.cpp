@@ -37,7 +37,7 @@ hipError_t launch_wf_intersect(const RenderParams &p, uint32_t grid, hipStream_t
 hipError_t launch_wf_shade(const RenderParams &p, uint32_t grid, hipStream_t stream);
 uint32_t wf_resident_waves(const RenderParams &p, bool shade);
 uint32_t wf_intersect_lds_bytes(const RenderParams &p);
-uint32_t stack_entry_bytes();
+uint32_t stack_entry_bytes(const RenderParams &p);
 uint32_t coop_ball_lds_bytes();
 hipError_t wf_intersect_attributes(const RenderParams &p, int *vgprs);
 hipError_t launch_selftest_div(float d, uint32_t lo_bits, uint32_t hi_bits, unsigned long long *d_mismatches, hipStream_t stream);
@@ -61,6 +61,8 @@ struct rtr_context {
     std::string error;
     rtr::BuildOptions build_options;
     int tree_kernel = 0; // option "tree_kernel": 0 auto, 1 resumable, 2 wave, 3 samples, 4 stream
+    uint32_t debug_lds_pad = 0; // option "debug_lds_pad"
+    bool stack_wide = false;    // option "stack_entries" = "wide"
     uint32_t wf_flush = 8; // option "stream_flush": finished walks a wave of k_wf_intersect collects before storing them
     void *d_wf = nullptr;  // streaming wavefront: the path records of one batch (ray, hit, state, chain, stage)
     size_t wf_cap = 0;
@@ -282,10 +284,14 @@ int launch_frame(rtr_context *ctx, const rtr_camera *camera, const rtr_settings 
             else p.chain_bits = 0xFFFFFFFFu; // ids
         }
     }
-    uint32_t lds_bytes = p.chain_lds * 64u * 4u + p.stack_cap * 64u * rtr::stack_entry_bytes() + (2u * p.sphere_regs + p.lds_materials) * 32u; // spheres, their materials' copies, the material table
+    // one-word stack entries when every index fits 16 bits (rtr_kernels.hip stack_pack32); option "stack_entries" = "wide" keeps
+    // the general form for tests
+    p.stack_packed = (p.sample_parallel && !streaming && !ctx->stack_wide && fs.nodes.size() <= 65536u && fs.leaf_hot.size() <= 65536u) ? 1u : 0u; // (the samples kernel has both forms)
+    uint32_t lds_bytes = p.chain_lds * 64u * 4u + p.stack_cap * 64u * rtr::stack_entry_bytes(p) + (2u * p.sphere_regs + p.lds_materials) * 32u; // spheres, their materials' copies, the material table
 #ifdef RTR_X_COOP_BALL
     if (p.sphere_regs) lds_bytes += rtr::coop_ball_lds_bytes(); // the wave-cooperative rejection sampler's scratch (experiment)
 #endif
+    lds_bytes += ctx->debug_lds_pad;
     if (lds_bytes > 160u * 1024u) return fail(ctx, RTR_ERR_UNSUPPORTED, "max_ray_depth + tree height exceed one CU's LDS");
     ctx->last_lds = lds_bytes;
     ctx->last_primary = 0;
@@ -634,6 +640,19 @@ int rtr_set_option(rtr_context *ctx, const char *name, const char *value) {
         const unsigned long long k = std::strtoull(v.c_str(), &end, 10);
         if (v.empty() || *end != '\0') return fail(ctx, RTR_ERR_INVALID_ARGUMENT, "debug_alloc_limit must be a byte count");
         ctx->debug_alloc_limit = k;
+        return RTR_OK;
+    }
+    if (n == "stack_entries") { // takes effect at the next render
+        if (v == "auto") ctx->stack_wide = false;
+        else if (v == "wide") ctx->stack_wide = true;
+        else return fail(ctx, RTR_ERR_INVALID_ARGUMENT, "stack_entries must be \"auto\" or \"wide\"");
+        return RTR_OK;
+    }
+    if (n == "debug_lds_pad") { // measuring aid: extra dynamic LDS bytes per workgroup (occupancy experiments)
+        char *end = nullptr;
+        const unsigned long k = std::strtoul(v.c_str(), &end, 10);
+        if (v.empty() || *end != '\0' || k > 65536ul) return fail(ctx, RTR_ERR_INVALID_ARGUMENT, "debug_lds_pad must be a byte count up to 65536");
+        ctx->debug_lds_pad = (uint32_t)k;
         return RTR_OK;
     }
     if (n == "debug_fault") { // testing aid: the following launches set the fault word

@@ -442,8 +442,18 @@ RTR_DEV void gather_fence(const float4 &a, const float4 &b, const float4 &c, con
 // Entry distances on the traversal stack.  They are read back for one purpose: to skip a deferred box that the best hit
 // has overtaken meanwhile (`e > best.cull`).  Any value not above the true entry distance keeps that test exact -- it can
 // only fail to skip, and the box's children are then tested against the best hit anyway -- so the stack keeps the upper
-// 16 bits of the f32 (truncation: toward zero, and entries are +0, positive, or -inf for "never skip").  Six bytes per
+// 16 bits of the f32 (truncation: toward zero; entries are positive, or +0 for "never skip").  Six bytes per
 // entry instead of eight: LDS per wave is what limits the tree kernels' occupancy (house.obj: 17 -> 23 waves per CU).
+// Small trees (at most 65 536 node records and 65 536 leaves: every BASELINE scene) pack an entry into ONE word: the ref's
+// four flag bits, a 16-bit index and the upper 12 bits of the distance (sign dropped: entries are never negative).  Four
+// bytes per entry instead of six, one LDS instruction per push and pop instead of two.  LDS is granted in 1280-byte
+// steps on gfx950 (measured: DESIGN.md section 5.2), so house.obj's 14 entries + tables went from 5632 B = 5 steps
+// = 25 waves per CU to 3840 B = 3 steps, where the 72 VGPRs' 28 waves fit.
+RTR_DEV uint32_t stack_pack32(uint32_t ref, float e) {
+    return (ref & 0xF0000000u) | ((ref & 0xFFFFu) << 12) | ((__float_as_uint(e) >> 19) & 0xFFFu);
+}
+RTR_DEV uint32_t stack_ref32(uint32_t w) { return (w & 0xF0000000u) | ((w >> 12) & 0xFFFFu); }
+RTR_DEV float stack_t32(uint32_t w) { return __uint_as_float((w & 0xFFFu) << 19); }
 #ifndef RTR_X_STACK_F32
 typedef uint16_t StackT;
 RTR_DEV StackT stack_t_pack(float e) { return (StackT)(__float_as_uint(e) >> 16); }
@@ -555,7 +565,7 @@ __device__ __forceinline__ bool lane_of(uint64_t mask) { return __builtin_amdgcn
 // The body exists ONCE, as a macro: the wave-synchronous walk (`traverse`), the resumable walk (k_render_bvh), the
 // sample-parallel walk (k_render_bvh_sp) and the streaming walk (k_wf_intersect) expand it in place -- as a function
 // shared by several callers it compiled 6 ... 18 % slower in each of them.  Names it expects in scope: p, lane, cur, sp,
-// best, inv, a, rng, stk_ref, stk_t and the template flags VOL, MESH.
+// best, inv, a, rng, stk_ref, stk_t, the template flags VOL, MESH and stack_packed (constexpr bool: one-word stack entries).
 //   RAY       the ray being walked
 //   TMAX_BOX  the tmax the reference hands to AABB::hit: +inf from the scene tree, closest_so_far when a mesh is reached
 //             from the linear world (scene.rs:147, mesh.rs:124-127)
@@ -628,10 +638,14 @@ __device__ __forceinline__ bool lane_of(uint64_t mask) { return __builtin_amdgcn
                 if (lvol_ && rvol_) sw_ = false; /* both subtrees draw: keep the reference's left-then-right order */    \
                 const uint32_t second_ = sw_ ? l_ : r_;                                                                  \
                 float esecond_ = sw_ ? el_ : er_;                                                                        \
-                if (sw_ ? lvol_ : rvol_) esecond_ = -__builtin_inff(); /* never culled at pop time */                    \
+                if (sw_ ? lvol_ : rvol_) esecond_ = 0.0f; /* never culled at pop time: no bound is below tmin */        \
                 cur = sw_ ? r_ : l_;                                                                                     \
-                stk_ref[sp * 64 + lane] = second_;                                                                       \
-                stk_t[sp * 64 + lane] = stack_t_pack(esecond_);                                                                      \
+                if constexpr (stack_packed) {                                                                            \
+                    stk_ref[sp * 64 + lane] = stack_pack32(second_, esecond_);                                           \
+                } else {                                                                                                 \
+                    stk_ref[sp * 64 + lane] = second_;                                                                   \
+                    stk_t[sp * 64 + lane] = stack_t_pack(esecond_);                                                      \
+                }                                                                                                        \
                 sp++;                                                                                                    \
             } else if (hl_) {                                                                                            \
                 cur = l_;                                                                                                \
@@ -657,9 +671,11 @@ __device__ __forceinline__ bool lane_of(uint64_t mask) { return __builtin_amdgcn
             while (sp > 0) {                                                                                             \
                 RTR_LS1(9) RTR_LS(10, true)                                                                              \
                 sp--;                                                                                                    \
-                const uint32_t c_ = stk_ref[sp * 64 + lane];                                                             \
-                const float e_ = stack_t_unpack(stk_t[sp * 64 + lane]);                                                                \
-                if (e_ > best.cull) continue; /* its box is entered beyond the best hit (never for -inf entries) */      \
+                uint32_t c_ = stk_ref[sp * 64 + lane];                                                                   \
+                float e_;                                                                                                \
+                if constexpr (stack_packed) { e_ = stack_t32(c_); c_ = stack_ref32(c_); }                                \
+                else e_ = stack_t_unpack(stk_t[sp * 64 + lane]);                                                         \
+                if (e_ > best.cull) continue; /* its box is entered beyond the best hit (never for 0 entries) */         \
                 cur = c_;                                                                                                \
                 got_ = true;                                                                                             \
                 break;                                                                                                   \
@@ -676,6 +692,7 @@ RTR_DEV void traverse(const RenderParams &p, uint32_t root, const Ray &r, V3 inv
     uint32_t sp = 0;
     uint32_t cur = root;
     bool walking = true;
+    constexpr bool stack_packed = false;
     while (walking) RTR_WALK_TRIP(r, tmax_box, walking = false)
 }
 
@@ -1736,6 +1753,7 @@ __global__ __launch_bounds__(64, RTR_X_BVH_WAVES) void k_render_bvh(const Render
     bool alive = s < spp;
     if (alive) { start_sample(s); begin_segment(); }
 
+    constexpr bool stack_packed = false;
     for (;;) {
         const uint64_t alive_mask = __ballot(alive);
         if (alive_mask == 0ull) break;
@@ -1801,7 +1819,7 @@ __global__ __launch_bounds__(64, RTR_X_BVH_WAVES) void k_render_bvh(const Render
 // Register budget: 7 waves per SIMD (72 VGPRs) for scenes without volumes -- with the lane states in scalar masks the
 // kernel needs 77, and the 7-wave build spills at most two (C1 +2.5 %, C3 +4 %, C4 -0.5 %: house.obj's 6 KB of stack
 // per wave allow 27 waves per CU either way); 6 waves for the volume kernels, which would spill 8 ... 25.
-template <uint32_t VOL, bool MESH>
+template <uint32_t VOL, bool MESH, bool PACKED>
 __attribute__((amdgpu_num_sgpr(128)))
 #ifndef RTR_X_SP_WAVES
 #define RTR_X_SP_WAVES (VOL == 0u ? 7 : 6)
@@ -1821,7 +1839,7 @@ __global__ __launch_bounds__(64, RTR_X_SP_WAVES) void k_render_bvh_sp(const Rend
     chain.init(lds, lane, p.chain_bits);
     uint32_t *stk_ref = lds + p.chain_lds * 64u;
     StackT *stk_t = reinterpret_cast<StackT *>(stk_ref + p.stack_cap * 64u);
-    uint32_t *lds_mat_base = reinterpret_cast<uint32_t *>(stk_t + p.stack_cap * 64u);
+    uint32_t *lds_mat_base = PACKED ? stk_ref + p.stack_cap * 64u : reinterpret_cast<uint32_t *>(stk_t + p.stack_cap * 64u);
     const uint32_t *lds_mats = p.lds_materials ? lds_mat_base : nullptr;
     if (p.lds_materials)
         for (uint32_t i = lane; i < p.lds_materials * 8u; i += 64u) lds_mat_base[i] = reinterpret_cast<const uint32_t *>(p.materials)[i];
@@ -1872,6 +1890,7 @@ __global__ __launch_bounds__(64, RTR_X_SP_WAVES) void k_render_bvh_sp(const Rend
     // converged: as per-lane bools carried round the loops they live in vector registers as bytes, re-tested and copied
     // on every trip.
     uint64_t walking_m = 0ull;
+    constexpr bool stack_packed = PACKED; // one-word stack entries (RenderParams::stack_packed, set for small trees)
     auto begin_segment = [&]() -> bool { // the head of world_hit<WORLD_BVH>; true = the lane has a walk to take
         nseg++;
         a = dot(ray.d, ray.d);
@@ -2125,6 +2144,7 @@ __global__ __launch_bounds__(64, RTR_X_WF_WAVES) void k_wf_intersect(const Rende
                 sc.tail += want < have ? want : have;
             }
         }
+        constexpr bool stack_packed = false;
         const uint64_t walkers = __ballot(walking);
         if (walkers == 0ull && __ballot(holding) == 0ull) break; // nothing in flight and nothing left to take
         // ---- walk: kWalkUnroll trips for every lane with a walk in progress ----
@@ -2352,8 +2372,13 @@ static uint32_t vol_level(const RenderParams &p) { return p.has_volumes > 2u ? 2
 static const void *render_kernel(const RenderParams &p) {
     const uint32_t v = vol_level(p), m = p.has_meshes ? 1u : 0u;
     if (p.world == WORLD_BVH && p.sample_parallel) {
-        static const void *const t[3][2] = RTR_TREE_TABLE(k_render_bvh_sp);
-        return t[v][m];
+        static const void *const wide[3][2] = {{RTR_FN(k_render_bvh_sp<0u, false, false>), RTR_FN(k_render_bvh_sp<0u, true, false>)},
+                                               {RTR_FN(k_render_bvh_sp<1u, false, false>), RTR_FN(k_render_bvh_sp<1u, true, false>)},
+                                               {RTR_FN(k_render_bvh_sp<2u, false, false>), RTR_FN(k_render_bvh_sp<2u, true, false>)}};
+        static const void *const packed[3][2] = {{RTR_FN(k_render_bvh_sp<0u, false, true>), RTR_FN(k_render_bvh_sp<0u, true, true>)},
+                                                 {RTR_FN(k_render_bvh_sp<1u, false, true>), RTR_FN(k_render_bvh_sp<1u, true, true>)},
+                                                 {RTR_FN(k_render_bvh_sp<2u, false, true>), RTR_FN(k_render_bvh_sp<2u, true, true>)}};
+        return p.stack_packed ? packed[v][m] : wide[v][m];
     }
     if (p.world == WORLD_BVH && p.resumable_walk) {
         static const void *const t[3][2] = RTR_TREE_TABLE(k_render_bvh);
@@ -2401,8 +2426,8 @@ hipError_t launch_wf_generate(const RenderParams &p, uint32_t batch_samples, hip
     hipLaunchKernelGGL(k_wf_generate, dim3(p.tiles_total, batch_samples), dim3(64), 0, stream, p);
     return hipGetLastError();
 }
-uint32_t wf_intersect_lds_bytes(const RenderParams &p) { return p.stack_cap * 64u * (4u + (uint32_t)sizeof(StackT)) + kWfRing * 4u; }
-uint32_t stack_entry_bytes() { return 4u + (uint32_t)sizeof(StackT); }
+uint32_t stack_entry_bytes(const RenderParams &p) { return p.stack_packed ? 4u : 4u + (uint32_t)sizeof(StackT); }
+uint32_t wf_intersect_lds_bytes(const RenderParams &p) { return p.stack_cap * 64u * stack_entry_bytes(p) + kWfRing * 4u; }
 uint32_t coop_ball_lds_bytes() { return kCoopWords * 4u; }
 // (the coop experiment's scratch, when built in, follows the sphere world's slot-material table)
 uint32_t wf_shade_lds_bytes(const RenderParams &p) { return (kWfRing + p.lds_materials * 8u) * 4u; }

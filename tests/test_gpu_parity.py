@@ -468,6 +468,33 @@ def test_sah_mesh_trees_render_the_same_frame(builder, w, h):
 
 
 @pytest.mark.parametrize("builder,w,h", [(lambda: house_scene(2), 160, 90), (lambda: simple_scene(4), 128, 128),
+                                         (lambda: monkey_scene(3), 96, 54)])
+def test_stack_entry_forms_render_the_same_frame(builder, w, h):
+    """The samples kernel keeps a traversal-stack entry in one word (4 flag bits, 16-bit index, 12 bits of entry
+    distance) when the tree has at most 65 536 nodes and leaves, else in a 32-bit ref plus a 16-bit distance (option
+    stack_entries = "wide" forces that form).  The distance is only a lower bound used to skip boxes the best hit has
+    overtaken, so both forms -- and the oracle's unculled walk -- must give the same frame; LDS per wave must shrink."""
+    scene = builder()
+    with rt.Renderer(0) as r:
+        r.set_option("tree_kernel", "samples")
+        r.upload_scene(scene)
+        rgba_p, mean_p = r.render(w, h, seed=77, want_rgba8=True, want_mean=True)
+        st_p = r.stats()
+        r.set_option("stack_entries", "wide")
+        rgba_w, mean_w = r.render(w, h, seed=77, want_rgba8=True, want_mean=True)
+        st_w = r.stats()
+        with pytest.raises(rt.RtrError):
+            r.set_option("stack_entries", "narrow")
+    assert st_p.segments == st_w.segments
+    assert st_p.lds_bytes < st_w.lds_bytes
+    assert np.array_equal(rgba_p, rgba_w)
+    assert np.array_equal(mean_p.view(np.uint32), mean_w.view(np.uint32))
+    o_rgba, o_mean, o_st = pyoracle.OracleScene(scene).render(w, h, 77, threads=0)
+    assert o_st.segments == st_p.segments
+    assert np.array_equal(rgba_p, o_rgba)
+
+
+@pytest.mark.parametrize("builder,w,h", [(lambda: house_scene(2), 160, 90), (lambda: simple_scene(4), 128, 128),
                                          (lambda: monkey_scene(2, bvh=False), 96, 54),
                                          (lambda: benchmark_scene(4, enable_bvh_tree=True), 128, 72)])
 def test_leaf_pairs_do_not_change_a_bit(builder, w, h):

@@ -270,7 +270,8 @@ def test_options_are_validated_without_a_device():
                                 ("sample_chunks", ["1", "7", "auto"], "0"),
                                 ("chunk_timeout_ms", ["0", "2.5", "10000"], "-1"), ("debug_fault", ["on", "off"], "1"),
                                 ("debug_alloc_limit", ["4096", "0"], "lots"),
-                                ("sky_filter", ["bilinear", "nearest"], "cubic")]:
+                                ("sky_filter", ["bilinear", "nearest"], "cubic"),
+                                ("stack_entries", ["wide", "auto"], "narrow"), ("debug_lds_pad", ["64", "0"], "many")]:
             for v in good:
                 r.set_option(name, v)
             with pytest.raises(rt.RtrError):
