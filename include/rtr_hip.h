@@ -243,6 +243,9 @@ int rtr_abi_version(void);
  *   "sky_filter" = "nearest" (default: SkyMap::sample, backgrounds.rs:84-92) | "bilinear": interpolate the four texels
  *                 around the direction (longitude wraps, latitude clamps).  An extension, not reference behaviour.
  *   "debug_fault" = "off" (default) | "on": testing aid; launches set the fault word themselves.
+ *   "block_samples" = "8" (default) | 1 .. 1024: the samples kernel runs one workgroup per resident wave; a wave whose lanes
+ *               ask for work claims the next block -- one 8x8 tile, this many consecutive samples -- from a counter in
+ *               device memory.  Any value gives the same frame.
  *   "stack_entries" = "auto" (default) | "wide": the samples kernel keeps a traversal-stack entry in one 32-bit word (4 flag
  *               bits, 16-bit index, 12 bits of entry distance) for trees of at most 65 536 nodes and leaves, else in a
  *               32-bit ref plus a 16-bit distance; "wide" forces the second form (tests).  The distance is a lower bound used

@@ -62,6 +62,8 @@ struct rtr_context {
     rtr::BuildOptions build_options;
     int tree_kernel = 0; // option "tree_kernel": 0 auto, 1 resumable, 2 wave, 3 samples, 4 stream
     uint32_t debug_lds_pad = 0; // option "debug_lds_pad"
+    uint32_t block_samples = 8; // option "block_samples": samples of one tile a wave of the samples kernel claims at a time
+    uint32_t *d_work = nullptr; // the samples kernel's block counter (one word, zeroed before every launch)
     bool stack_wide = false;    // option "stack_entries" = "wide"
     uint32_t wf_flush = 8; // option "stream_flush": finished walks a wave of k_wf_intersect collects before storing them
     void *d_wf = nullptr;  // streaming wavefront: the path records of one batch (ray, hit, state, chain, stage)
@@ -405,7 +407,18 @@ int launch_frame(rtr_context *ctx, const rtr_camera *camera, const rtr_settings 
             b.chunks = std::max(1u, std::min(p.chunks, b.sample_count));
             const bool first = done == 0u, last = done + b.sample_count == sample_count;
             if (!streaming) {
-                RTR_HIP_TRY(ctx, rtr::launch_render(b, grid * b.chunks, lds_bytes, stream));
+                // one workgroup per wave the device keeps resident; the waves claim blocks of (tile, block_samples samples) from a
+                // counter (measured at 1080p / 256 spp: 1: +45 %, 2: +3 ... 8 %, 4: +1 %, 8: best, 16: +1 %, 32: +5 %, 64: +13 %)
+                if (!ctx->d_work) RTR_HIP_TRY(ctx, hipMalloc((void **)&ctx->d_work, 256));
+                RTR_HIP_TRY(ctx, hipMemsetAsync(ctx->d_work, 0, sizeof(uint32_t), stream));
+                b.work_counter = ctx->d_work;
+                b.samples_per_block = ctx->block_samples;
+                const uint64_t blocks = (uint64_t)grid * ((b.sample_count + b.samples_per_block - 1u) / b.samples_per_block);
+                if (blocks > 0xFFFFFFF0ull) return fail(ctx, RTR_ERR_UNSUPPORTED, "too many work blocks in one batch: lower samples_batch");
+                b.work_blocks = (uint32_t)blocks;
+                b.chunks = 1u;
+                const uint32_t resident = std::max(1u, rtr::render_resident_waves(b, lds_bytes));
+                RTR_HIP_TRY(ctx, rtr::launch_render(b, (uint32_t)std::min<uint64_t>(resident, blocks), lds_bytes, stream));
             } else {
                 // the batch's path records, carved out of one allocation (16-byte aligned pieces first)
                 const uint64_t n = wf_paths_per_sample * b.sample_count;
@@ -505,6 +518,7 @@ void rtr_destroy(rtr_context *ctx) {
         if (ctx->d_carry) (void)hipFree(ctx->d_carry);
         if (ctx->d_samples) (void)hipFree(ctx->d_samples);
         if (ctx->d_wf) (void)hipFree(ctx->d_wf);
+        if (ctx->d_work) (void)hipFree(ctx->d_work);
         if (ctx->d_chunk_flags) (void)hipFree(ctx->d_chunk_flags);
         if (ctx->d_rgba8) (void)hipFree(ctx->d_rgba8);
         if (ctx->d_mean) (void)hipFree(ctx->d_mean);
@@ -640,6 +654,13 @@ int rtr_set_option(rtr_context *ctx, const char *name, const char *value) {
         const unsigned long long k = std::strtoull(v.c_str(), &end, 10);
         if (v.empty() || *end != '\0') return fail(ctx, RTR_ERR_INVALID_ARGUMENT, "debug_alloc_limit must be a byte count");
         ctx->debug_alloc_limit = k;
+        return RTR_OK;
+    }
+    if (n == "block_samples") { // takes effect at the next render
+        char *end = nullptr;
+        const unsigned long k = std::strtoul(v.c_str(), &end, 10);
+        if (v.empty() || *end != '\0' || k < 1ul || k > 1024ul) return fail(ctx, RTR_ERR_INVALID_ARGUMENT, "block_samples must be an integer in [1, 1024]");
+        ctx->block_samples = (uint32_t)k;
         return RTR_OK;
     }
     if (n == "stack_entries") { // takes effect at the next render

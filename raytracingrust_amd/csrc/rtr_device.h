@@ -104,6 +104,9 @@ struct RenderParams {
     uint32_t resumable_walk; // WORLD_BVH: k_render_bvh (per-lane walk state machine) instead of k_render
     uint32_t has_volumes;   // 0: no Volume objects; 1: sphere-bounded ones (kernels instantiated with the visit-order rules);
                             // 2: mesh-bounded ones too (those kernels plus the nested mesh walk of Volume::hit)
+    uint32_t *work_counter; // sample-parallel kernel: the next unclaimed block of (tile, group of samples_per_block samples)
+    uint32_t work_blocks;   // blocks of this launch: tiles_launch * ceil(sample_count / samples_per_block)
+    uint32_t samples_per_block;
     uint32_t stack_packed; // 1: a traversal-stack entry is one word -- 4 flag bits, a 16-bit index, 12 bits of entry distance
     uint32_t stack_pad;    //    (trees of at most 65 536 nodes and leaves); 0: a 32-bit ref plus a 16-bit distance
     const DevNode *nodes;

@@ -1827,9 +1827,6 @@ __attribute__((amdgpu_num_sgpr(128)))
 __global__ __launch_bounds__(64, RTR_X_SP_WAVES) void k_render_bvh_sp(const RenderParams p) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const uint32_t lane = threadIdx.x;
-    const uint32_t chunk = blockIdx.x / p.tiles_launch, tidx = blockIdx.x - chunk * p.tiles_launch;
-    const uint32_t tile = tidx * p.n_shards + p.shard;
-    if (tile >= p.tiles_total) return;
 #ifdef RTR_X_LANESTAT
     if (lane < 32u) rtr_lsc[lane] = 0u;
     __builtin_amdgcn_s_waitcnt(0);
@@ -1846,19 +1843,23 @@ __global__ __launch_bounds__(64, RTR_X_SP_WAVES) void k_render_bvh_sp(const Rend
     __builtin_amdgcn_s_waitcnt(0);
     __builtin_amdgcn_wave_barrier();
 
-    const uint32_t tx = tile % p.tiles_x, ty = tile / p.tiles_x;
+    // Work is claimed, not assigned: the launch is one workgroup per wave the device keeps resident, and a wave whose lanes
+    // ask for work takes the next block -- one tile, samples_per_block consecutive samples: 64 (sample, pixel) pairs per
+    // sample, sample-major, so the lanes that start together start on one sample's coherent primary rays -- from a
+    // counter in device memory (one returning atomic per block: ~28 per microsecond at 1080p, a third of what a counter
+    // word sustains).  With a fixed share per wave (round 2's first form: tile x sample range) every one of ~550 000
+    // waves paid its own set-up and its own ragged end; now those are paid once per resident wave.
+    uint32_t tx = 0u, ty = 0u;                         // the current block's tile (wave-uniform)
     const V3 cam_o = ld3(p.cam_origin), cam_h = ld3(p.cam_horizontal), cam_v = ld3(p.cam_vertical), cam_llc = ld3(p.cam_llc);
-    // the lane's current work item: one sample of one pixel of the tile
+    // the lane's current work item: one sample of one pixel of a tile
     uint32_t hp = 0;
     float fx = 0.0f, fy = 0.0f;
     uint64_t slot = 0; // where the sample's radiance goes: [sample - sample_begin][pixel]
     Rng rng;
     rng.inc = 1u; rng.state = 0u;
     uint32_t nseg = 0;
-    const uint32_t s_first = p.sample_begin + chunk_boundary(p.sample_count, chunk, p.chunks, 0u);
-    const uint32_t s_last = p.sample_begin + chunk_boundary(p.sample_count, chunk + 1u, p.chunks, 0u);
-    const uint32_t n_items = 64u * (s_last - s_first); // (sample, pixel) pairs of this workgroup, sample-major
-    uint32_t next_item = 0;                            // wave-uniform
+    uint32_t s_first = 0u, n_items = 0u, next_item = 0u; // the current block: its first sample, its pairs, the next unclaimed one
+    bool pool_empty = false;                             // (all wave-uniform)
     uint32_t depth = 0;
     Ray ray;
     ray.o = cam_o; ray.d = cam_o;
@@ -1911,13 +1912,28 @@ __global__ __launch_bounds__(64, RTR_X_SP_WAVES) void k_render_bvh_sp(const Rend
     auto fetch_work = [&]() { // hand the next items to the lanes that ask, in lane order; wave-uniform control flow
         bool began = false;
         while (need_m != 0ull) {
+            if (next_item >= n_items) { // the block is used up: claim the next one (wave-uniform)
+                if (pool_empty) { need_m = 0ull; break; } // nothing is left: the asking lanes retire
+                uint32_t id = 0u;
+                if (lane == 0u) id = atomicAdd(p.work_counter, 1u);
+                id = __builtin_amdgcn_readfirstlane(id);
+                if (id >= p.work_blocks) { pool_empty = true; need_m = 0ull; break; }
+                const uint32_t group = id / p.tiles_launch, tile = (id - group * p.tiles_launch) * p.n_shards + p.shard;
+                tx = tile % p.tiles_x; ty = tile / p.tiles_x;
+                const uint32_t s0 = group * p.samples_per_block;
+                s_first = p.sample_begin + s0;
+                n_items = 64u * (p.sample_count - s0 < p.samples_per_block ? p.sample_count - s0 : p.samples_per_block);
+                next_item = 0u;
+            }
             const uint64_t asking = need_m;
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(asking >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)asking, 0u));
             const uint32_t item = next_item + rank;
             next_item += (uint32_t)__popcll(asking);
             bool again = false, got = false;
             if (lane_of(asking)) {
-                if (item < n_items) { // else nothing is left: the lane retires
+                if (item >= n_items) {
+                    again = true; // past the end of the block: ask again, from the next one
+                } else {
                     const uint32_t pix = item & 63u, si = s_first + (item >> 6);
                     const uint32_t x = tx * 8u + (pix & 7u), y = ty * 8u + (pix >> 3);
                     if (x < p.width && y < p.height) {

@@ -467,6 +467,24 @@ def test_sah_mesh_trees_render_the_same_frame(builder, w, h):
     assert c["mismatched_pixels"] <= 5, c
 
 
+@pytest.mark.parametrize("builder,w,h", [(lambda: house_scene(5), 157, 83), (lambda: simple_scene(7), 61, 130)])
+def test_claimed_work_blocks_do_not_change_a_bit(builder, w, h):
+    """The samples kernel's waves claim blocks of (tile, block_samples consecutive samples) from a device counter.  Which
+    wave and lane renders a (sample, pixel) pair must not matter: block sizes that divide the sample count, that do not,
+    and that exceed it -- on frames with ragged tile edges -- give the oracle's frame bit for bit."""
+    scene = builder()
+    o_rgba, o_mean, o_st = pyoracle.OracleScene(scene).render(w, h, 31, threads=0)
+    with rt.Renderer(0) as r:
+        r.set_option("tree_kernel", "samples")
+        r.upload_scene(scene)
+        for bs in ("1", "2", "3", "8", "1024"):
+            r.set_option("block_samples", bs)
+            rgba, mean = r.render(w, h, seed=31, want_rgba8=True, want_mean=True)
+            assert r.stats().segments == o_st.segments, bs
+            assert np.array_equal(rgba, o_rgba), bs
+            assert np.array_equal(mean.view(np.uint32), o_mean.view(np.uint32)), bs
+
+
 @pytest.mark.parametrize("builder,w,h", [(lambda: house_scene(2), 160, 90), (lambda: simple_scene(4), 128, 128),
                                          (lambda: monkey_scene(3), 96, 54)])
 def test_stack_entry_forms_render_the_same_frame(builder, w, h):

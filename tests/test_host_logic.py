@@ -271,7 +271,7 @@ def test_options_are_validated_without_a_device():
                                 ("chunk_timeout_ms", ["0", "2.5", "10000"], "-1"), ("debug_fault", ["on", "off"], "1"),
                                 ("debug_alloc_limit", ["4096", "0"], "lots"),
                                 ("sky_filter", ["bilinear", "nearest"], "cubic"),
-                                ("stack_entries", ["wide", "auto"], "narrow"), ("debug_lds_pad", ["64", "0"], "many")]:
+                                ("stack_entries", ["wide", "auto"], "narrow"), ("block_samples", ["1", "64", "8"], "0"), ("debug_lds_pad", ["64", "0"], "many")]:
             for v in good:
                 r.set_option(name, v)
             with pytest.raises(rt.RtrError):
