@@ -359,6 +359,7 @@ int launch_frame(rtr_context *ctx, const rtr_camera *camera, const rtr_settings 
             budget = std::max<uint64_t>(per_sample_total, ((uint64_t)free_b + held) / 2ull);
         }
         uint64_t fit = std::max<uint64_t>(1ull, std::min<uint64_t>(budget / per_sample_total, (16ull << 30) / per_sample));
+        fit = std::max<uint64_t>(1ull, std::min<uint64_t>(fit, 0xFFFFFFFFull / ((uint64_t)width * height))); // 32-bit (sample, pixel) slots in the kernels
         if (streaming) fit = std::min<uint64_t>(fit, std::min<uint64_t>(0x7FFFFFFFull / wf_paths_per_sample, 65535ull));
         if (streaming && fit > 64ull) fit = 64ull; // more samples per batch buy nothing: a batch is ~15 launches
         batch_samples = (uint32_t)std::max<uint64_t>(1ull, std::min<uint64_t>(sample_count, fit));

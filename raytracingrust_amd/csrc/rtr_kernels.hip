@@ -1854,7 +1854,7 @@ __global__ __launch_bounds__(64, RTR_X_SP_WAVES) void k_render_bvh_sp(const Rend
     // the lane's current work item: one sample of one pixel of a tile
     uint32_t hp = 0;
     float fx = 0.0f, fy = 0.0f;
-    uint64_t slot = 0; // where the sample's radiance goes: [sample - sample_begin][pixel]
+    uint32_t slot = 0; // where the sample's radiance goes: [sample - sample_begin][pixel] (a batch has fewer than 2^32 pairs)
     Rng rng;
     rng.inc = 1u; rng.state = 0u;
     uint32_t nseg = 0;
@@ -1908,7 +1908,7 @@ __global__ __launch_bounds__(64, RTR_X_SP_WAVES) void k_render_bvh_sp(const Rend
     };
     uint64_t alive_m = 0ull;
     uint64_t need_m = wave_mask(true); // the lanes that want the workgroup's next (sample, pixel) pair
-    const uint64_t n_pixels = (uint64_t)p.width * p.height;
+    const uint32_t n_pixels = p.width * p.height;
     auto fetch_work = [&]() { // hand the next items to the lanes that ask, in lane order; wave-uniform control flow
         bool began = false;
         while (need_m != 0ull) {
@@ -1941,7 +1941,7 @@ __global__ __launch_bounds__(64, RTR_X_SP_WAVES) void k_render_bvh_sp(const Rend
                         fx = (float)x; fy = (float)y;
                         hp = hash32(pixel ^ p.seed_key0);
                         rng.inc = (hash32(hp + p.seed_key1) << 1) | 1u;
-                        slot = (uint64_t)(si - p.sample_begin) * n_pixels + pixel;
+                        slot = (si - p.sample_begin) * n_pixels + pixel;
                         got = true;
                         start_sample(si);
                         began = begin_segment();
