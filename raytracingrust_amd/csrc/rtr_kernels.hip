@@ -1812,13 +1812,14 @@ __global__ __launch_bounds__(64, RTR_X_BVH_WAVES) void k_render_bvh(const Render
 
 // ---- WORLD_BVH, samples instead of pixels ------------------------------------------------------------------------
 // k_render_bvh ties a lane to one pixel because the pixel's samples are SUMMED in order -- but they need not be RENDERED
-// in order.  Here a workgroup owns (tile, sample range) and its lanes take (sample, pixel) pairs from a wave-level
-// counter as they finish; each sample's clamped radiance is written to p.samples[sample][pixel], and k_sum_samples adds
-// a pixel's samples in index order afterwards (the same additions as calculate_pixel's loop).  No lane waits for its
-// tile's slowest pixel, and sample ranges need no hand-over between workgroups.
+// in order.  Here the launch is one workgroup (one wave) per wave the device keeps resident; a wave claims blocks of
+// (tile, a few consecutive samples) from a counter in device memory and its lanes take the block's (sample, pixel) pairs
+// as they finish (ballot + mbcnt hand-out); each sample's clamped radiance is written to p.samples[sample][pixel], and
+// k_sum_samples adds a pixel's samples in index order afterwards (the same additions as calculate_pixel's loop).  No lane
+// waits for its tile's slowest pixel, no wave for a slower one, and nothing is handed over between workgroups.
 // Register budget: 7 waves per SIMD (72 VGPRs) for scenes without volumes -- with the lane states in scalar masks the
-// kernel needs 77, and the 7-wave build spills at most two (C1 +2.5 %, C3 +4 %, C4 -0.5 %: house.obj's 6 KB of stack
-// per wave allow 27 waves per CU either way); 6 waves for the volume kernels, which would spill 8 ... 25.
+// kernel needs 77, and the 7-wave build spills a few registers outside the walk (C1 +2.5 %, C3 +4 %); 6 waves for the
+// volume kernels, which would spill 8 ... 25.
 template <uint32_t VOL, bool MESH, bool PACKED>
 __attribute__((amdgpu_num_sgpr(128)))
 #ifndef RTR_X_SP_WAVES
