@@ -1651,7 +1651,7 @@ __global__ __launch_bounds__(64, WORLD == WORLD_LINEAR_SPHERES ? RTR_X_SPHERE_WA
 #define RTR_TREE_QUORUM_NUM 5
 #endif
 #ifndef RTR_TREE_QUORUM_NUM_SPHERES
-#define RTR_TREE_QUORUM_NUM_SPHERES 3
+#define RTR_TREE_QUORUM_NUM_SPHERES 2
 #endif
 #ifndef RTR_TREE_QUORUM_DEN
 #define RTR_TREE_QUORUM_DEN 8
@@ -1960,8 +1960,9 @@ __global__ __launch_bounds__(64, RTR_X_SP_WAVES) void k_render_bvh_sp(const Rend
 
     for (;;) {
         if (alive_m == 0ull) break;
-        // walk while more than 5/8 of the live lanes are walking in mesh scenes, 3/8 in sphere scenes, whose shading rounds
-        // are short next to a trip (102 spheres: +2.5 % over 5/8; meshes: 3/8 ... 6/8 within 2 %, 5/8 best)
+        // walk while more than 5/8 of the live lanes are walking in mesh scenes, 2/8 in sphere scenes, whose shading rounds
+        // are short next to a trip (102 spheres: 0 / 1 / 2 / 3 / 4 eighths 13.8 / 14.3 / 14.4 / 14.1 / 13.9 Grays/s;
+        // meshes: 4/8 ... 6/8 within 2 %, 5/8 best on house.obj, 4/8 on monkey.obj)
         const uint32_t quorum = (uint32_t)__popcll(alive_m) * (MESH ? RTR_TREE_QUORUM_NUM : RTR_TREE_QUORUM_NUM_SPHERES) / RTR_TREE_QUORUM_DEN;
         RTR_LS1(0) RTR_LS(15, lane_of(alive_m))
         // ---- walk: one trip per iteration for every lane still walking ----
