@@ -215,8 +215,10 @@ int rtr_abi_version(void);
  *                 walks the tree when enable_bvh_tree is set.  "wave": a wave returns from world.hit when its slowest
  *                 lane has finished.  "resumable": the walk is a per-lane state machine inside the main loop, so lanes
  *                 that are done shade and start their next ray while the others keep walking.  "samples": the same
- *                 walk, but a lane takes (sample, pixel) pairs of its tile instead of owning one pixel; each sample's
- *                 clamped radiance is written to device memory (16 bytes per sample, in batches of at most 16 GiB)
+ *                 walk, but a lane takes (sample, pixel) pairs instead of owning one pixel -- the launch is one workgroup
+ *                 per resident wave, and a wave claims blocks of (tile, "block_samples" samples) from a device counter; each
+ *                 sample's clamped radiance is written to device memory (16 bytes per sample, in batches of at most 16 GiB
+ *                 and fewer than 2^32 (sample, pixel) pairs)
  *                 and a second kernel adds every pixel's samples in index order.  "stream": the streaming wavefront --
  *                 the paths of a batch of samples live in device memory (65 + 4 * max_ray_depth bytes each) and every
  *                 stage is its own kernel: generate, then per recursion depth an intersect kernel whose lanes take the
