@@ -327,9 +327,10 @@ int launch_frame(rtr_context *ctx, const rtr_camera *camera, const rtr_settings 
             const uint32_t resident = std::max(1u, rtr::render_resident_waves(p, lds_bytes));
             const uint32_t min_len = p.world == rtr::WORLD_LINEAR_SPHERES ? 64u : 16u;
             uint32_t by_length = sample_count / min_len;
-            // a tapered pair (7/8 + 1/8 of the samples) already pays at 32 samples: 1080p 2.51 -> 2.46 ms at 32 spp,
-            // 4.65 -> 4.46 at 64, 9.32 -> 8.38 at 128 (what a rank of the 8-, 4- and 2-GPU sample split renders)
-            if (p.world == rtr::WORLD_LINEAR_SPHERES && sample_count >= 32u) by_length = std::max(by_length, 2u);
+            // a tapered pair (7/8 + 1/8 of the samples) pays from about 48 samples on (1080p, end of round 2: 32 samples 2.14 ms
+            // in one piece, 2.22 in two; 64 samples 4.04 / 3.82; 128 samples: see DESIGN.md section 6 -- what a rank of the 8-,
+            // 4- and 2-GPU sample split renders)
+            if (p.world == rtr::WORLD_LINEAR_SPHERES && sample_count >= 48u) by_length = std::max(by_length, 2u);
             if (grid >= 2u * resident) want = std::min(std::min(4u, 24u * resident / grid), by_length);
         }
         want = std::max(1u, std::min(want, std::max(1u, sample_count)));
