@@ -91,13 +91,34 @@ def free_port() -> int:
         return int(s.getsockname()[1])
 
 
+def visible_gpus() -> int:
+    """GPU agents of the KFD topology (nodes with a non-zero simd_count), capped by the *_VISIBLE_DEVICES lists -- read
+    from sysfs, so the launcher parent never initialises a GPU (a torch call here could, depending on the build)."""
+    n = 0
+    base = "/sys/class/kfd/kfd/topology/nodes"
+    try:
+        for node in os.listdir(base):
+            try:
+                with open(os.path.join(base, node, "properties")) as fh:
+                    props = dict(line.split()[:2] for line in fh if len(line.split()) >= 2)
+                if int(props.get("simd_count", "0")) > 0:
+                    n += 1
+            except (OSError, ValueError):
+                continue
+    except OSError:
+        return 0
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
+
+
 def spawn_ranks(args) -> int:
     """Called before any HIP / torch.cuda use in this process: starts args.gpus fresh rank processes (never re-execs a
     process that has touched the GPU) and returns their exit code.  Rank 0 prints the JSON line on the shared stdout."""
     if not plumbing_mode():
-        import torch
-
-        have = torch.cuda.device_count()  # counts devices without initialising one (brief, Environment)
+        have = visible_gpus()  # from sysfs: nothing in the launcher process opens KFD / HSA
         if have < args.gpus:
             sys.stderr.write(f"bench.py: --gpus {args.gpus} but only {have} GPU(s) are visible; refusing to run on fewer\n")
             return 2
@@ -241,31 +262,69 @@ def cpu_baseline(scene, width, height, spp_sample, seed):
 
 def other_configs(r, torch, dev, stream, seed):
     """Short secondary measurements, reported beside the headline so that the driver's record carries them too:
-    BASELINE's tree-world configurations (C1 simple.json, C3 monkey + HDRI, C4 house + plane + HDRI at 1920x1080, C5
-    simple.json + HDRI at 3840x2160) at 256 spp, one warm-up frame and two timed frames each through the same
-    device-resident entry point.  Flat scalars."""
+    BASELINE's tree-world configurations (C1 simple.json, C3 glass monkey + HDRI, C4 house + plane + HDRI at 1920x1080, C5
+    simple.json + HDRI at 3840x2160).  Per configuration: (a) a full-size frame at 4 spp rendered on the GPU and by the
+    oracle on the same seed, compared byte for byte and segment for segment -> `cN_parity`; (b) one warm-up frame and two
+    timed frames at 256 spp through the device-resident entry point; (c) for C3 and C5 one timed frame at the spp BASELINE
+    states (512 / 1024).  Flat scalars."""
+    import numpy as np
+
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pyoracle
     from raytracingrust_amd.configs import baseline_config
 
+    cores = len(os.sched_getaffinity(0))
     out = {}
-    for name in ("c1", "c3", "c4", "c5"):
+
+    def timed(W, H, rgba8, frames, first_seed, scene=None):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(frames):
+            r.render_frame_device(W, H, first_seed + i, rgba8.data_ptr(), stream, scene=scene)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / frames
+        return dt, float(r.segment_counts()[-frames:].mean())
+
+    for name, stated_spp in (("c1", 256), ("c3", 512), ("c4", 256), ("c5", 1024)):
         scene, W, H = baseline_config(name, 256)
         r.upload_scene(scene)
         rgba8 = torch.zeros((H, W, 4), dtype=torch.uint8, device=dev)
+        # (a) parity at full size, low spp: the checker renders the same seed (polynomial trig: the kernels' own, DESIGN 3)
+        low = copy_settings(scene, 4)
+        r.render_frame_device(W, H, seed, rgba8.data_ptr(), stream, scene=low)
+        torch.cuda.synchronize()
+        g_seg, g_rgba = int(r.segment_counts()[-1]), rgba8.cpu().numpy()
+        o_rgba, _, o_st = pyoracle.OracleScene(low, trig_mode=pyoracle.TRIG_POLY).render(W, H, seed, threads=cores, want_rgba8=True, want_mean=False)
+        bad = int(np.count_nonzero(np.any(g_rgba != o_rgba, axis=-1)))
+        out[name + "_parity"] = "bit-exact" if bad == 0 and g_seg == int(o_st.segments) else "MISMATCH"
+        out[name + "_parity_detail"] = f"{W}x{H} at 4 spp: {bad} RGBA8 pixels differ; segments GPU {g_seg} vs oracle {int(o_st.segments)}"
+        # (b) 256 spp
         r.render_frame_device(W, H, seed, rgba8.data_ptr(), stream)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for i in range(2):
-            r.render_frame_device(W, H, seed + 1 + i, rgba8.data_ptr(), stream)
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / 2.0
-        seg = float(r.segment_counts()[-2:].mean())
+        dt, seg = timed(W, H, rgba8, 2, seed + 1)
         out[name + "_mrays_per_s"] = round(seg / dt / 1e6, 1)
         out[name + "_ms_per_frame"] = round(dt * 1e3, 3)
         out[name + "_segments_per_frame"] = int(seg)
-    out["note"] = ("256 spp, reference (median-split) trees, tree_kernel auto; 1920x1080: C1 simple.json 102 spheres, C3 monkey.obj + "
-                   "plane + synthetic HDRI, C4 house.obj + plane + synthetic HDRI depth 3; 3840x2160: C5 simple.json + HDRI (BASELINE "
-                   "quotes C3 at 512 and C5 at 1024 spp: 2x / 4x the frame time at the same rate); full lines: python bench.py --config cN")
+        # (c) BASELINE's stated spp
+        if stated_spp != 256:
+            full = copy_settings(scene, stated_spp)
+            dt, seg = timed(W, H, rgba8, 1, seed + 7, scene=full)
+            out[f"{name}_{stated_spp}spp_mrays_per_s"] = round(seg / dt / 1e6, 1)
+            out[f"{name}_{stated_spp}spp_ms_per_frame"] = round(dt * 1e3, 3)
+        del rgba8
+    out["note"] = ("reference (median-split) trees, tree_kernel auto; 1920x1080: C1 simple.json 102 spheres, C3 glass monkey.obj + "
+                   "plane + synthetic HDRI, C4 house.obj + plane + synthetic HDRI depth 3; 3840x2160: C5 simple.json + HDRI; cN_* at 256 "
+                   "spp (two timed frames), cN_<spp>spp_* one timed frame at BASELINE's stated spp, cN_parity: a full-size 4-spp frame "
+                   "against the oracle on the same seed in this run; full lines: python bench.py --config cN")
     return out
+
+
+def copy_settings(scene, spp):
+    import copy
+
+    sc = copy.copy(scene)
+    sc.settings = copy.copy(scene.settings)
+    sc.settings.samples_per_pixel = spp
+    return sc
 
 
 def main():

@@ -44,8 +44,9 @@
 extern "C" {
 #endif
 
-/* 2: volumes, rtr_set_option.  3: rtr_selftest_div, options "leaf_pairs"; structs unchanged since 2. */
-#define RTR_ABI_VERSION 4
+/* 2: volumes, rtr_set_option.  3: rtr_selftest_div, options "leaf_pairs".  4: mesh-bounded volumes.
+ * 5: rtr_create_multi -- one context over several GPUs --, rtr_probe_hits, rtr_camera_ray_origin, traversal counters in rtr_stats. */
+#define RTR_ABI_VERSION 5
 
 typedef enum rtr_status {
     RTR_OK = 0,
@@ -314,7 +315,8 @@ int rtr_kernel_times_ms(rtr_context *ctx, float *out, uint32_t cap);
 /* The same launches: HIP-event time from the start of each launch to the end of its (last) integrate kernel, i.e.
  * without the k_sum_samples pass of the "samples" tree kernel.  bench.py prices the dominant kernel with it. */
 int rtr_integrate_times_ms(rtr_context *ctx, float *out, uint32_t cap);
-/* Name of the integrate kernel the most recent render launched (as rocprofv3 lists it, with a gloss). */
+/* Name of the integrate kernel the most recent render launched (as rocprofv3 lists it, with a gloss).  The pointer is to a
+ * per-thread copy: valid until the calling thread's next rtr_kernel_name call. */
 const char *rtr_kernel_name(const rtr_context *ctx);
 /* Device self-test: the kernels' correctly-rounded square root (csrc/rtr_kernels.hip rt_sqrt) against the
  * compiler's sqrtf() over all 2^32 f32 bit patterns; *mismatches must come back 0. */
@@ -327,6 +329,28 @@ int rtr_selftest_div(rtr_context *ctx, float denominator, uint32_t numerator_lo_
                      uint64_t *mismatches);
 /* Device-counted ray segments of the same launches, in the same order. */
 int rtr_segment_counts(rtr_context *ctx, uint64_t *out, uint32_t cap);
+
+/* --- introspection of the path's closed forms (known-answer tests run them on the product, not on a restatement) --- */
+
+/* HitRecord, lib/utils/ray.rs:29-54, as world.hit returns it to trace_ray (render.rs:38) */
+typedef struct rtr_hit {
+    uint32_t hit;        /* 0: None -- the other fields are then unspecified */
+    float t;
+    float point[3];
+    float normal[3];     /* face-forwarded (ray.rs:45-49) */
+    uint32_t front_face;
+    uint32_t material;   /* MaterialHandle */
+    uint32_t reserved[2];
+} rtr_hit;
+/* world.hit(ray, 0.00001, +inf) (render.rs:38) of the uploaded scene for n_rays caller-supplied rays (origins, directions:
+ * n_rays * 3 floats, host memory; directions need not be normalised, as in the reference), on the device, through the same
+ * code the render kernels inline: the BvhTree walk (bvh.rs:43-50,146-199) when enable_bvh_tree, else Scene::hit's linear scan
+ * (scene.rs:141-157).  A Volume's random draw (volume.rs:57) comes from the stream (seed, pixel = ray index, sample 0). */
+int rtr_probe_hits(rtr_context *ctx, uint32_t enable_bvh_tree, uint64_t seed, uint32_t n_rays, const float *origins,
+                   const float *directions, rtr_hit *out);
+/* Camera::ray_origin (lib/core/camera.rs:37-56): out = origin[3], horizontal[3], vertical[3], lower_left_corner[3] -- the
+ * values every launch derives from rtr_camera.  Host arithmetic (the reference's tan is host code too); needs no context. */
+int rtr_camera_ray_origin(const rtr_camera *camera, float out[12]);
 
 #ifdef __cplusplus
 }

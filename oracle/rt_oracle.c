@@ -1068,6 +1068,12 @@ void or_probe_rng(uint64_t seed, uint32_t pixel, uint32_t sample, int kind, floa
         uint32_t s = or_rng_u32(&r);
         for (int i = 0; i < n; i++) out[i] = or_ball_coord(&s);
     }
+    if (kind == 3) { /* n / 3 successive calls of sample_unit_sphere_volume on the stream: the accepted points */
+        for (int i = 0; i + 2 < n; i += 3) {
+            v3 v = sample_unit_sphere_volume(&r);
+            out[i] = v.x; out[i + 1] = v.y; out[i + 2] = v.z;
+        }
+    }
 }
 float or_probe_acos(float x, int trig_mode) { return or_acos(x, trig_mode); }
 float or_probe_atan2(float y, float x, int trig_mode) { return or_atan2(y, x, trig_mode); }

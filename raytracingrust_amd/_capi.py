@@ -71,6 +71,11 @@ class rtr_stats(C.Structure):
                 ("vgprs", C.c_uint32), ("lds_bytes", C.c_uint32), ("block_threads", C.c_uint32)]
 
 
+class rtr_hit(C.Structure):
+    _fields_ = [("hit", C.c_uint32), ("t", C.c_float), ("point", c_float3), ("normal", c_float3),
+                ("front_face", C.c_uint32), ("material", C.c_uint32), ("reserved", C.c_uint32 * 2)]
+
+
 RTR_OK = 0
 STATUS_NAMES = {
     0: "RTR_OK", -1: "RTR_ERR_INVALID_ARGUMENT", -2: "RTR_ERR_NO_DEVICE", -3: "RTR_ERR_HIP", -4: "RTR_ERR_BAD_INDEX",
@@ -110,6 +115,8 @@ SYMBOLS = [
     ("rtr_kernel_name", C.c_char_p, [_ctx]),
     ("rtr_selftest_sqrt", C.c_int, [_ctx, C.POINTER(C.c_uint64)]),
     ("rtr_selftest_div", C.c_int, [_ctx, C.c_float, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]),
+    ("rtr_probe_hits", C.c_int, [_ctx, C.c_uint32, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p, C.POINTER(rtr_hit)]),
+    ("rtr_camera_ray_origin", C.c_int, [C.POINTER(rtr_camera), C.POINTER(C.c_float)]),
 ]
 
 _lib = None

@@ -35,7 +35,9 @@ def kernel_sha() -> str:
     import hashlib
 
     h = hashlib.sha256()
-    for name in ("rtr_kernels.hip", "rtr_device.h", "rtr_api.cpp"):  # (rtr_lbvh.hip builds trees, it does not render)
+    # every source and header of the library: the flattener (rtr_scene.*) and the device builder (rtr_lbvh.hip) decide the
+    # tree layout the kernels walk -- leaf pairs, splits, stack depth -- and with it LDS per wave, occupancy and counters
+    for name in SOURCES + HEADERS:
         with open(os.path.join(CSRC, name), "rb") as fh:
             h.update(fh.read())
     h.update(" ".join(FLAGS).encode())

@@ -41,6 +41,7 @@ uint32_t stack_entry_bytes(const RenderParams &p);
 uint32_t coop_ball_lds_bytes();
 hipError_t wf_intersect_attributes(const RenderParams &p, int *vgprs);
 hipError_t launch_selftest_div(float d, uint32_t lo_bits, uint32_t hi_bits, unsigned long long *d_mismatches, hipStream_t stream);
+hipError_t launch_probe_hits(const RenderParams &p, const float *d_origins, const float *d_dirs, uint32_t n, uint32_t *d_out, hipStream_t stream);
 } // namespace rtr
 
 #ifndef RTR_BVH_LDS_MATERIALS
@@ -76,6 +77,7 @@ struct rtr_context {
     void *d_samples = nullptr; // k_render_bvh_sp: one float4 per (sample, pixel) of a launch
     uint32_t samples_batch = 0;  // option "samples_batch": samples per batch of that buffer (0: as many as 16 GiB hold)
     size_t samples_cap = 0;
+    uint64_t budget_key = 0, budget_bytes = 0; // memory budget of the per-sample buffers, looked up once per launch shape
     void *d_carry = nullptr;       // float4 per pixel: running sums between sample chunks
     size_t carry_cap = 0;
     void *d_chunk_flags = nullptr; // per tile + 1
@@ -186,6 +188,36 @@ int ensure_scratch(rtr_context *ctx, void **buf, size_t *cap, size_t need) {
     return RTR_OK;
 }
 
+// The scene's part of the launch parameters: which world render.rs:68-72 selects and where its records live in HBM.
+void set_world_params(const rtr_context *ctx, bool enable_bvh_tree, rtr::RenderParams &p) {
+    const rtr::FlatScene &fs = ctx->flat;
+    // render.rs:68-72: the tree when enable_bvh_tree, else the linear scan of scene.rs:141-157
+    // stack entries: a walk pushes at most once per node record on its path (FlatScene::stack_depth, checked by
+    // tests/cpp/scene_sanity.cpp); one more where a Volume's nested mesh walk starts above the outer walk's entries.
+    // Exact, because LDS per wave bounds the tree kernels' occupancy: house.obj 6016 -> 5632 B = 27 -> 28 waves per CU.
+    if (enable_bvh_tree) { p.world = rtr::WORLD_BVH; p.stack_cap = std::max(1u, fs.stack_depth + (fs.has_volumes ? 1u : 0u)); }
+    else if (fs.spheres_only) { p.world = rtr::WORLD_LINEAR_SPHERES; p.stack_cap = 0u; }
+    else { p.world = rtr::WORLD_LINEAR_GENERIC; p.stack_cap = fs.mesh_stack_depth + 1u; }
+    p.n_objects = fs.n_objects;
+    p.has_volumes = fs.has_volumes ? (fs.has_mesh_volumes ? 2u : 1u) : 0u; // 2: the kernels with the nested mesh walk
+    p.has_meshes = fs.n_triangles > 0u ? 1u : 0u;
+    p.root_ref = fs.root_ref;
+    std::memcpy(p.root_box, fs.root_box, sizeof p.root_box);
+    p.nodes = static_cast<const rtr::DevNode *>(ctx->d_nodes);
+    p.leaf_hot = static_cast<const rtr::DevLeafHot *>(ctx->d_leaf_hot);
+    p.leaf_cold = static_cast<const rtr::DevLeafCold *>(ctx->d_leaf_cold);
+    p.lin_spheres = static_cast<const rtr::DevLinSphere *>(ctx->d_lin);
+    p.objects = static_cast<const rtr::DevObject *>(ctx->d_objects);
+    p.materials = static_cast<const rtr::DevMaterial *>(ctx->d_materials);
+    p.n_materials = (uint32_t)fs.materials.size();
+    p.bg_kind = fs.bg_kind;
+    std::memcpy(p.bg_a, fs.bg_a, sizeof p.bg_a);
+    std::memcpy(p.bg_b, fs.bg_b, sizeof p.bg_b);
+    p.sky = static_cast<const float *>(ctx->d_sky);
+    p.sky_w = fs.sky_w; p.sky_h = fs.sky_h;
+    p.sky_bilinear = ctx->sky_bilinear ? 1u : 0u;
+}
+
 // Fill the launch parameters and launch the integrator.  Exactly one of (sum_rgba) / (rgba8|mean_rgb) is used.
 int launch_frame(rtr_context *ctx, const rtr_camera *camera, const rtr_settings *st, uint32_t width, uint32_t height,
                  uint64_t seed, uint32_t shard, uint32_t n_shards, float *d_sum_rgba, uint8_t *d_rgba8, float *d_mean_rgb,
@@ -213,20 +245,11 @@ int launch_frame(rtr_context *ctx, const rtr_camera *camera, const rtr_settings 
     p.sample_begin = sample_begin; p.sample_count = sample_count;
     p.clamp_indirect = st->clamp_indirect;
     seed_keys(seed, p.seed_key0, p.seed_key1);
-    // render.rs:68-72: the tree when enable_bvh_tree, else the linear scan of scene.rs:141-157
-    // stack entries: a walk pushes at most once per node record on its path (FlatScene::stack_depth, checked by
-    // tests/cpp/scene_sanity.cpp); one more where a Volume's nested mesh walk starts above the outer walk's entries.
-    // Exact, because LDS per wave bounds the tree kernels' occupancy: house.obj 6016 -> 5632 B = 27 -> 28 waves per CU.
-    if (st->enable_bvh_tree) { p.world = rtr::WORLD_BVH; p.stack_cap = std::max(1u, fs.stack_depth + (fs.has_volumes ? 1u : 0u)); }
-    else if (fs.spheres_only) { p.world = rtr::WORLD_LINEAR_SPHERES; p.stack_cap = 0u; }
-    else { p.world = rtr::WORLD_LINEAR_GENERIC; p.stack_cap = fs.mesh_stack_depth + 1u; }
-    p.n_objects = fs.n_objects;
-    p.has_volumes = fs.has_volumes ? (fs.has_mesh_volumes ? 2u : 1u) : 0u; // 2: the kernels with the nested mesh walk
+    set_world_params(ctx, st->enable_bvh_tree != 0u, p);
     // "auto": the resumable walk (k_render_bvh) for scenes with meshes.  Measured against the wave-synchronous
     // k_render<BVH>: +45 % on house.obj, +10 % on monkey.obj; on sphere-only trees equal within 2 % (reference trees)
     // or 7 % behind (SAH trees), so those keep k_render.
     p.resumable_walk = (ctx->tree_kernel == 1 || (ctx->tree_kernel == 0 && fs.n_triangles > 0u)) ? 1u : 0u;
-    p.has_meshes = fs.n_triangles > 0u ? 1u : 0u;
     // "samples" (and "auto" whenever it applies): lanes take (sample, pixel) pairs and each sample's radiance goes
     // through HBM (k_render_bvh_sp + k_sum_samples).  Needs a tree world, something to trace and the fused or
     // sample-sharded path (a tile shard writes into a frame other shards share); otherwise the resumable / wave rule.
@@ -239,21 +262,6 @@ int launch_frame(rtr_context *ctx, const rtr_camera *camera, const rtr_settings 
     p.sample_parallel = ((ctx->tree_kernel == 3 || (ctx->tree_kernel == 0 && fs.leaf_hot.size() >= 32u)) && per_sample_ok) ? 1u : 0u;
     if ((ctx->tree_kernel == 3 || ctx->tree_kernel == 4) && !p.sample_parallel && !streaming) p.resumable_walk = 1u;
     if (streaming) p.sample_parallel = 1u; // shares the per-sample radiance buffer and k_sum_samples with "samples"
-    p.root_ref = fs.root_ref;
-    std::memcpy(p.root_box, fs.root_box, sizeof p.root_box);
-    p.nodes = static_cast<const rtr::DevNode *>(ctx->d_nodes);
-    p.leaf_hot = static_cast<const rtr::DevLeafHot *>(ctx->d_leaf_hot);
-    p.leaf_cold = static_cast<const rtr::DevLeafCold *>(ctx->d_leaf_cold);
-    p.lin_spheres = static_cast<const rtr::DevLinSphere *>(ctx->d_lin);
-    p.objects = static_cast<const rtr::DevObject *>(ctx->d_objects);
-    p.materials = static_cast<const rtr::DevMaterial *>(ctx->d_materials);
-    p.n_materials = (uint32_t)fs.materials.size();
-    p.bg_kind = fs.bg_kind;
-    std::memcpy(p.bg_a, fs.bg_a, sizeof p.bg_a);
-    std::memcpy(p.bg_b, fs.bg_b, sizeof p.bg_b);
-    p.sky = static_cast<const float *>(ctx->d_sky);
-    p.sky_w = fs.sky_w; p.sky_h = fs.sky_h;
-    p.sky_bilinear = ctx->sky_bilinear ? 1u : 0u;
     p.tiles_x = (width + 7u) / 8u;
     uint32_t tiles_y = (height + 7u) / 8u;
     p.tiles_total = p.tiles_x * tiles_y;
@@ -353,12 +361,22 @@ int launch_frame(rtr_context *ctx, const rtr_camera *camera, const rtr_settings 
             wf_bytes_per_path = 32ull + 16ull + 16ull + 4ull * p.max_depth + 1ull;
             per_sample_total += wf_paths_per_sample * wf_bytes_per_path;
         }
-        size_t free_b = 0, total_b = 0;
-        uint64_t budget = 16ull << 30;
-        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-            const uint64_t held = (uint64_t)ctx->samples_cap + (uint64_t)ctx->wf_cap; // ours already: reusable
-            budget = std::max<uint64_t>(per_sample_total, ((uint64_t)free_b + held) / 2ull);
+        // The memory budget is looked up when the launch shape changes (or after an allocation failure), not per frame:
+        // hipMemGetInfo inside every launch made the batch depend on what else the process had allocated meanwhile (torch's
+        // caching allocator, say), and a batch that grew mid-run frees and reallocates the buffer -- a device synchronisation
+        // in the middle of a pipelined run.  In steady state the batch never changes.
+        const uint64_t shape_key = ((uint64_t)width << 40) ^ ((uint64_t)height << 20) ^ ((uint64_t)sample_count << 8) ^ ((uint64_t)p.max_depth << 1) ^ (streaming ? 1ull : 0ull);
+        if (ctx->budget_key != shape_key || ctx->budget_bytes == 0) {
+            size_t free_b = 0, total_b = 0;
+            uint64_t fresh = 16ull << 30;
+            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+                const uint64_t held = (uint64_t)ctx->samples_cap + (uint64_t)ctx->wf_cap; // ours already: reusable
+                fresh = ((uint64_t)free_b + held) / 2ull;
+            }
+            ctx->budget_key = shape_key;
+            ctx->budget_bytes = std::max<uint64_t>(fresh, 1ull);
         }
+        const uint64_t budget = std::max<uint64_t>(per_sample_total, ctx->budget_bytes);
         uint64_t fit = std::max<uint64_t>(1ull, std::min<uint64_t>(budget / per_sample_total, (16ull << 30) / per_sample));
         fit = std::max<uint64_t>(1ull, std::min<uint64_t>(fit, 0xFFFFFFFFull / ((uint64_t)width * height))); // 32-bit (sample, pixel) slots in the kernels
         if (streaming) fit = std::min<uint64_t>(fit, std::min<uint64_t>(0x7FFFFFFFull / wf_paths_per_sample, 65535ull));
@@ -372,6 +390,7 @@ int launch_frame(rtr_context *ctx, const rtr_camera *camera, const rtr_settings 
             if (batch_samples == 1u) return rc;
             (void)hipGetLastError(); // out of memory: the same frame in smaller batches
             batch_samples = std::max(1u, batch_samples / 2u);
+            ctx->budget_bytes = std::max<uint64_t>(1ull, per_sample_total * batch_samples); // remembered for this shape
         }
         p.samples = static_cast<float *>(ctx->d_samples);
         if (batch_samples < sample_count) { // running sums between batches
@@ -868,7 +887,45 @@ int rtr_integrate_times_ms(rtr_context *ctx, float *out, uint32_t cap) {
 const char *rtr_kernel_name(const rtr_context *ctx) {
     if (!ctx) return "";
     RTR_LOCK(ctx);
-    return ctx->kernel_name.c_str();
+    thread_local std::string copy; // the caller's own copy: a render on another thread cannot invalidate it
+    copy = ctx->kernel_name;
+    return copy.c_str();
+}
+
+int rtr_camera_ray_origin(const rtr_camera *camera, float out[12]) {
+    if (!camera || !out) return RTR_ERR_INVALID_ARGUMENT;
+    rtr::camera_ray_origin(*camera, out, out + 3, out + 6, out + 9);
+    return RTR_OK;
+}
+
+int rtr_probe_hits(rtr_context *ctx, uint32_t enable_bvh_tree, uint64_t seed, uint32_t n_rays, const float *origins, const float *directions,
+                   rtr_hit *out) {
+    if (!ctx) return RTR_ERR_INVALID_ARGUMENT;
+    RTR_LOCK(ctx);
+    static_assert(sizeof(rtr_hit) == 48, "k_probe_hits writes 12 words per ray");
+    if (ctx->device < 0) return fail(ctx, RTR_ERR_NO_DEVICE, "host-only context: no HIP device bound (there is no CPU fallback)");
+    if (!ctx->have_scene) return fail(ctx, RTR_ERR_NO_SCENE, "rtr_upload_scene has not been called");
+    if (n_rays == 0u) return RTR_OK;
+    if (!origins || !directions || !out || n_rays > (1u << 24)) return fail(ctx, RTR_ERR_INVALID_ARGUMENT, "bad probe arguments");
+    RTR_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    rtr::RenderParams p;
+    std::memset(&p, 0, sizeof p);
+    set_world_params(ctx, enable_bvh_tree != 0u, p);
+    seed_keys(seed, p.seed_key0, p.seed_key1);
+    if (p.stack_cap * 64u * 6u > 64u * 1024u) return fail(ctx, RTR_ERR_UNSUPPORTED, "tree height exceeds the probe kernel's LDS");
+    const size_t in_bytes = (size_t)n_rays * 3u * sizeof(float), out_bytes = (size_t)n_rays * sizeof(rtr_hit);
+    void *d = nullptr;
+    RTR_HIP_TRY(ctx, hipMalloc(&d, 2u * in_bytes + out_bytes));
+    float *d_o = static_cast<float *>(d), *d_d = d_o + (size_t)n_rays * 3u;
+    uint32_t *d_out = reinterpret_cast<uint32_t *>(d_d + (size_t)n_rays * 3u);
+    hipError_t e = hipMemcpyAsync(d_o, origins, in_bytes, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_d, directions, in_bytes, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = rtr::launch_probe_hits(p, d_o, d_d, n_rays, d_out, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, out_bytes, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail_hip(ctx, e, "rtr_probe_hits");
+    return RTR_OK;
 }
 
 int rtr_selftest_sqrt(rtr_context *ctx, uint64_t *mismatches) {

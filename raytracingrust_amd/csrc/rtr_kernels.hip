@@ -698,6 +698,7 @@ RTR_DEV void traverse(const RenderParams &p, uint32_t root, const Ray &r, V3 inv
 
 struct Hit {
     V3 point, normal;
+    float t; // (read by k_probe_hits only: dead, hence free, in the render kernels)
     bool front_face;
     uint32_t material;
     uint32_t slot; // sphere world with an LDS table: the winner's slot, which also addresses a copy of its material record
@@ -714,6 +715,7 @@ template <uint32_t VOL>
 RTR_DEV void finish_leaf(const RenderParams &p, const Best &best, const Ray &r, Hit &h) {
     uint32_t L = best.leaf & REF_INDEX;
     const float4 *cold = reinterpret_cast<const float4 *>(p.leaf_cold + L);
+    h.t = best.t;
     h.point = add(r.o, scale(r.d, best.t));
     float4 c0 = cold[0];
     h.material = __float_as_uint(c0.w);
@@ -841,6 +843,7 @@ RTR_DEV bool world_hit(const RenderParams &p, const Ray &r, Hit &h, uint32_t *st
         const float4 w = *reinterpret_cast<const float4 *>(lds_spheres + best * 8); // centre, radius
         h.material = lds_spheres[best * 8 + 5];
         h.slot = (uint32_t)best;
+        h.t = closest;
         h.point = add(r.o, scale(r.d, closest));
         const V3 pc = sub(h.point, mk(w.x, w.y, w.z));
         V3 outward;
@@ -868,6 +871,7 @@ RTR_DEV bool world_hit(const RenderParams &p, const Ray &r, Hit &h, uint32_t *st
         }
         if (best < 0) return false;
         const DevLinSphere &s = p.lin_spheres[best];
+        h.t = closest;
         h.point = add(r.o, scale(r.d, closest));
         V3 outward = divs(sub(h.point, mk(s.center[0], s.center[1], s.center[2])), s.radius);
         face_forward(h, r, outward);
@@ -2330,6 +2334,47 @@ __global__ __launch_bounds__(256) void k_resolve(const float *sum_rgba, uint32_t
         uint32_t r8 = sat_u8(sqrtf(r) * 255.0f), g8 = sat_u8(sqrtf(g) * 255.0f), b8 = sat_u8(sqrtf(b) * 255.0f);
         reinterpret_cast<uint32_t *>(rgba8)[i] = r8 | (g8 << 8) | (b8 << 16) | (255u << 24);
     }
+}
+
+// rtr_probe_hits: world.hit (render.rs:38: tmin = 0.00001, tmax = +inf) for caller-supplied rays, one lane per ray, through
+// the same world_hit the render kernels inline.  Closed-form known answers of Sphere::hit / Triangle::hit / the tree walk
+// are asserted on the HIP path through it (tests/kat_cases.py), without the oracle in between.  A Volume's random draw
+// (volume.rs:57) comes from the stream of (seed keys, pixel = ray index, sample 0).
+// out: 12 words per ray = rtr_hit {hit, t, point[3], normal[3], front_face, material, 0, 0}.  LDS: the traversal stack.
+template <uint32_t WORLD, uint32_t VOL, bool MESH>
+__global__ __launch_bounds__(64) void k_probe_hits(const RenderParams p, const float *origins, const float *dirs, uint32_t n, uint32_t *out) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const uint32_t lane = threadIdx.x, i = blockIdx.x * 64u + lane;
+    if (i >= n) return;
+    uint32_t *stk_ref = lds;
+    StackT *stk_t = reinterpret_cast<StackT *>(stk_ref + p.stack_cap * 64u);
+    Ray ray;
+    ray.o = ld3(origins + 3ull * i);
+    ray.d = ld3(dirs + 3ull * i);
+    const uint32_t hp = hash32(i ^ p.seed_key0);
+    Rng rng;
+    rng.inc = (hash32(hp + p.seed_key1) << 1) | 1u;
+    rng.state = hash32(hp);
+    Hit h;
+    h.point = ray.o; h.normal = ray.o; h.t = 0.0f; h.front_face = false; h.material = 0u; h.slot = 0u;
+    const SphereRegs<0> sr = {};
+    const bool hit = world_hit<WORLD, 0u, VOL, MESH>(p, ray, h, stk_ref, stk_t, lane, sr, nullptr, rng);
+    uint32_t *o = out + 12ull * i;
+    o[0] = hit ? 1u : 0u;
+    o[1] = hit ? __float_as_uint(h.t) : 0u;
+    o[2] = __float_as_uint(h.point.x); o[3] = __float_as_uint(h.point.y); o[4] = __float_as_uint(h.point.z);
+    o[5] = __float_as_uint(h.normal.x); o[6] = __float_as_uint(h.normal.y); o[7] = __float_as_uint(h.normal.z);
+    o[8] = h.front_face ? 1u : 0u;
+    o[9] = h.material;
+    o[10] = 0u; o[11] = 0u;
+}
+hipError_t launch_probe_hits(const RenderParams &p, const float *d_origins, const float *d_dirs, uint32_t n, uint32_t *d_out, hipStream_t stream) {
+    const uint32_t lds_bytes = p.stack_cap * 64u * (4u + (uint32_t)sizeof(StackT));
+    const dim3 grid((n + 63u) / 64u), block(64);
+    if (p.world == WORLD_BVH) hipLaunchKernelGGL((k_probe_hits<WORLD_BVH, 2u, true>), grid, block, lds_bytes, stream, p, d_origins, d_dirs, n, d_out);
+    else if (p.world == WORLD_LINEAR_GENERIC) hipLaunchKernelGGL((k_probe_hits<WORLD_LINEAR_GENERIC, 2u, true>), grid, block, lds_bytes, stream, p, d_origins, d_dirs, n, d_out);
+    else hipLaunchKernelGGL((k_probe_hits<WORLD_LINEAR_SPHERES, 0u, false>), grid, block, lds_bytes, stream, p, d_origins, d_dirs, n, d_out);
+    return hipGetLastError();
 }
 
 // Exhaustive device self-test: rt_sqrt(x) against sqrtf(x) for every f32 bit pattern (NaNs compare as NaNs).

@@ -209,12 +209,42 @@ class Renderer:
         self._check(self._lib.rtr_selftest_div(self._ctx, C.c_float(denominator), lo_bits, hi_bits, C.byref(bad)))
         return int(bad.value)
 
+    def probe_hits(self, origins, directions, enable_bvh_tree: Optional[bool] = None, seed: int = 0):
+        """world.hit(ray, 0.00001, inf) (render.rs:38) of the uploaded scene for caller-supplied rays, on the device.
+        Returns one dict per ray (t, point, normal, front_face, material) or None for a miss."""
+        o = np.ascontiguousarray(origins, dtype=np.float32).reshape(-1, 3)
+        d = np.ascontiguousarray(directions, dtype=np.float32).reshape(-1, 3)
+        assert o.shape == d.shape
+        if enable_bvh_tree is None:
+            enable_bvh_tree = bool(self._scene.settings.enable_bvh_tree) if self._scene is not None else True
+        out = (_capi.rtr_hit * max(len(o), 1))()
+        self._check(self._lib.rtr_probe_hits(self._ctx, 1 if enable_bvh_tree else 0, C.c_uint64(seed), len(o),
+                                             o.ctypes.data_as(C.c_void_p), d.ctypes.data_as(C.c_void_p), out))
+        res = []
+        for i in range(len(o)):
+            h = out[i]
+            res.append(None if not h.hit else {
+                "t": float(np.float32(h.t)), "point": np.array(list(h.point), dtype=np.float32),
+                "normal": np.array(list(h.normal), dtype=np.float32), "front_face": bool(h.front_face),
+                "material": int(h.material)})
+        return res
+
     def segment_counts(self, cap: int = 64) -> np.ndarray:
         out = np.zeros(cap, dtype=np.uint64)
         n = self._lib.rtr_segment_counts(self._ctx, out.ctypes.data_as(C.POINTER(C.c_uint64)), cap)
         if n < 0:
             self._check(n)
         return out[:n]
+
+
+def camera_ray_origin(camera) -> np.ndarray:
+    """Camera::ray_origin (lib/core/camera.rs:37-56) as the library computes it: rows origin, horizontal, vertical,
+    lower_left_corner.  Host arithmetic; needs no device."""
+    out = (C.c_float * 12)()
+    rc = _capi.load().rtr_camera_ray_origin(C.byref(camera_struct(camera)), out)
+    if rc != _capi.RTR_OK:
+        raise _capi.RtrError(rc, "rtr_camera_ray_origin")
+    return np.array(list(out), dtype=np.float32).reshape(4, 3)
 
 
 def render(target: RenderTarget, scene: Scene, seed: int = DEFAULT_SEED, device: int = 0) -> None:

@@ -362,10 +362,12 @@ def test_sample_sharded_frame_matches_within_float_sum_order(gpu_renderer, n_sha
         r.render_samples_device(w, h, seed, 10, 4, total.data_ptr(), 0)  # 10 + 4 > 13
 
 
-@pytest.mark.parametrize("config,spp", [("c1", 2), ("c4", 1), ("c3l", 1)])
+@pytest.mark.parametrize("config,spp", [("c1", 2), ("c4", 1), ("c3l", 1), ("c3", 1), ("c5", 1)])
 def test_full_size_frames_against_the_oracle(gpu_renderer, config, spp):
-    """BASELINE's frame size (1920x1080) for the tree worlds -- C1 (simple.json), C4 (house + plane, mix material, HDRI)
-    and C3's geometry (monkey + plane, HDRI) -- at low spp, whole frame against the oracle (polynomial trig mode)."""
+    """BASELINE's frame sizes for the tree worlds -- 1920x1080: C1 (simple.json), C4 (house + plane, mix material, HDRI), C3
+    (glass monkey + plane, HDRI: the benched configuration) and its Lambertian variant; 3840x2160: C5 (simple.json + HDRI:
+    129 600 tiles, 8.3 M (sample, pixel) slots per sample) -- at low spp, whole frame against the oracle (polynomial trig
+    mode)."""
     from raytracingrust_amd.configs import baseline_config
 
     scene, w, h = baseline_config(config, spp)

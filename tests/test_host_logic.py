@@ -23,7 +23,19 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), f"librtr_hip.so does not export {name}"
     bound = {n for n, _, _ in _capi.SYMBOLS}
     assert declared == bound, declared ^ bound
-    assert _capi.load().rtr_abi_version() == 4
+    assert _capi.load().rtr_abi_version() == 5
+
+
+@pytest.mark.parametrize("case", __import__("kat_cases").HOST_CASES, ids=lambda c: c.__name__)
+def test_host_known_answers_on_the_product(case):
+    """Camera::ray_origin and the BVH builder's tree shape, asserted on librtr_hip.so's host code (no device needed)."""
+    import kat_cases
+
+    b = kat_cases.HipBackend(-1)
+    try:
+        case(b)
+    finally:
+        b.close()
 
 
 def test_struct_layouts_match_the_header():
@@ -32,6 +44,7 @@ def test_struct_layouts_match_the_header():
     assert C.sizeof(_capi.rtr_settings) == 24 and C.sizeof(_capi.rtr_mesh) == 40
     assert C.sizeof(_capi.rtr_background) == 48 and C.sizeof(_capi.rtr_scene_desc) == 64 + 48 + 16
     assert C.sizeof(_capi.rtr_volume) == 32  # ABI 4: + boundary_kind, boundary_mesh
+    assert C.sizeof(_capi.rtr_hit) == 48
 
 
 def test_host_only_context_refuses_to_render():
