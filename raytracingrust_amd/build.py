@@ -15,7 +15,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "_lib")
 LIB_PATH = os.path.join(LIB_DIR, "librtr_hip.so")
 
-SOURCES = ["rtr_api.cpp", "rtr_scene.cpp", "rtr_kernels.hip", "rtr_lbvh.hip"]
+SOURCES = ["rtr_api.cpp", "rtr_scene.cpp", "rtr_kernels.hip", "rtr_lbvh.hip", "rtr_sort.hip"]
 HEADERS = ["rtr_device.h", "rtr_scene.h", os.path.join("..", "..", "include", "rtr_hip.h")]
 
 # -ffp-contract=off + correctly rounded divide/sqrt: the kernels must round like the reference's f32 code

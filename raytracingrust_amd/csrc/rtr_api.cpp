@@ -38,7 +38,6 @@ hipError_t launch_wf_shade(const RenderParams &p, uint32_t grid, hipStream_t str
 uint32_t wf_resident_waves(const RenderParams &p, bool shade);
 uint32_t wf_intersect_lds_bytes(const RenderParams &p);
 uint32_t stack_entry_bytes(const RenderParams &p);
-uint32_t coop_ball_lds_bytes();
 hipError_t wf_intersect_attributes(const RenderParams &p, int *vgprs);
 hipError_t launch_selftest_div(float d, uint32_t lo_bits, uint32_t hi_bits, unsigned long long *d_mismatches, hipStream_t stream);
 hipError_t launch_probe_hits(const RenderParams &p, const float *d_origins, const float *d_dirs, uint32_t n, uint32_t *d_out, hipStream_t stream);
@@ -64,7 +63,7 @@ struct rtr_context {
     int tree_kernel = 0; // option "tree_kernel": 0 auto, 1 resumable, 2 wave, 3 samples, 4 stream
     uint32_t debug_lds_pad = 0; // option "debug_lds_pad"
     uint32_t block_samples = 8; // option "block_samples": samples of one tile a wave of the samples kernel claims at a time
-    uint32_t *d_work = nullptr; // the samples kernel's block counter (one word, zeroed before every launch)
+    uint32_t *d_work = nullptr; // the integrate kernels' ticket counter (one word, zeroed before every launch)
     bool stack_wide = false;    // option "stack_entries" = "wide"
     uint32_t wf_flush = 8; // option "stream_flush": finished walks a wave of k_wf_intersect collects before storing them
     void *d_wf = nullptr;  // streaming wavefront: the path records of one batch (ray, hit, state, chain, stage)
@@ -298,9 +297,6 @@ int launch_frame(rtr_context *ctx, const rtr_camera *camera, const rtr_settings 
     // the general form for tests
     p.stack_packed = (p.sample_parallel && !streaming && !ctx->stack_wide && fs.nodes.size() <= 65536u && fs.leaf_hot.size() <= 65536u) ? 1u : 0u; // (the samples kernel has both forms)
     uint32_t lds_bytes = p.chain_lds * 64u * 4u + p.stack_cap * 64u * rtr::stack_entry_bytes(p) + (2u * p.sphere_regs + p.lds_materials) * 32u; // spheres, their materials' copies, the material table
-#ifdef RTR_X_COOP_BALL
-    if (p.sphere_regs) lds_bytes += rtr::coop_ball_lds_bytes(); // the wave-cooperative rejection sampler's scratch (experiment)
-#endif
     lds_bytes += ctx->debug_lds_pad;
     if (lds_bytes > 160u * 1024u) return fail(ctx, RTR_ERR_UNSUPPORTED, "max_ray_depth + tree height exceed one CU's LDS");
     ctx->last_lds = lds_bytes;
@@ -319,7 +315,7 @@ int launch_frame(rtr_context *ctx, const rtr_camera *camera, const rtr_settings 
     // Sample chunks (rtr_kernels.hip "Sample chunks").  They only pay when the launch is short of work items: auto aims
     // at ~24 items per resident wave, at most 4 chunks, each long enough to dwarf a workgroup's prologue (64 samples in
     // the sphere world, 16 in the tree worlds), and only for launches of at least two tiles per resident wave -- a
-    // chunk's workgroups must be dispatched after its predecessors have finished, or they spin in each other's way
+    // chunk's workgroups should start after their predecessors have finished, or they spin in each other's way
     // (measured: 1080p/256 spp 18.6 -> 16.9 ms with 4 chunks; 4K, small frames and short sample ranges lose).
     p.tiles_launch = grid > 0u ? grid : 1u;
     p.chunks = 1u;
@@ -408,7 +404,14 @@ int launch_frame(rtr_context *ctx, const rtr_camera *camera, const rtr_settings 
     }
     RTR_HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters + slot, 0, sizeof(unsigned long long), stream));
     RTR_HIP_TRY(ctx, hipEventRecord(ctx->ev_start[slot], stream));
-    if (grid > 0 && !p.sample_parallel) RTR_HIP_TRY(ctx, rtr::launch_render(p, grid * p.chunks, lds_bytes, stream));
+    if (grid > 0 && !p.sample_parallel) {
+        // One workgroup (one wave) per ticket -- (chunk, tile), chunk-major; a workgroup claims its ticket from the counter
+        // when it starts running (rtr_kernels.hip "Tickets and sample chunks": forward progress without any dispatch order).
+        p.work_counter = ctx->d_work;
+        p.work_blocks = p.tiles_launch * p.chunks;
+        RTR_HIP_TRY(ctx, hipMemsetAsync(ctx->d_work, 0, sizeof(uint32_t), stream));
+        RTR_HIP_TRY(ctx, rtr::launch_render(p, p.work_blocks, lds_bytes, stream));
+    }
     if (!p.sample_parallel) RTR_HIP_TRY(ctx, hipEventRecord(ctx->ev_mid[slot], stream));
     if (grid == 0 && p.sample_parallel) RTR_HIP_TRY(ctx, hipEventRecord(ctx->ev_mid[slot], stream));
     if (grid > 0 && p.sample_parallel) {
@@ -430,7 +433,6 @@ int launch_frame(rtr_context *ctx, const rtr_camera *camera, const rtr_settings 
             if (!streaming) {
                 // one workgroup per wave the device keeps resident; the waves claim blocks of (tile, block_samples samples) from a
                 // counter (measured at 1080p / 256 spp: 1: +45 %, 2: +3 ... 8 %, 4: +1 %, 8: best, 16: +1 %, 32: +5 %, 64: +13 %)
-                if (!ctx->d_work) RTR_HIP_TRY(ctx, hipMalloc((void **)&ctx->d_work, 256));
                 RTR_HIP_TRY(ctx, hipMemsetAsync(ctx->d_work, 0, sizeof(uint32_t), stream));
                 b.work_counter = ctx->d_work;
                 b.samples_per_block = ctx->block_samples;
@@ -516,8 +518,10 @@ int rtr_create(int device, rtr_context **out) {
     }
     if ((e = hipEventCreate(&ctx->ev_res_start)) != hipSuccess) return bail(e, "hipEventCreate");
     if ((e = hipEventCreate(&ctx->ev_res_stop)) != hipSuccess) return bail(e, "hipEventCreate");
+    // kRing segment counters and the sticky fault word
     if ((e = hipMalloc((void **)&ctx->d_counters, (kRing + 1) * sizeof(unsigned long long))) != hipSuccess) return bail(e, "hipMalloc");
     if ((e = hipMemset(ctx->d_counters, 0, (kRing + 1) * sizeof(unsigned long long))) != hipSuccess) return bail(e, "hipMemset");
+    if ((e = hipMalloc((void **)&ctx->d_work, 256)) != hipSuccess) return bail(e, "hipMalloc");
     *out = ctx;
     return RTR_OK;
 }

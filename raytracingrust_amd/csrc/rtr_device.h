@@ -104,8 +104,9 @@ struct RenderParams {
     uint32_t resumable_walk; // WORLD_BVH: k_render_bvh (per-lane walk state machine) instead of k_render
     uint32_t has_volumes;   // 0: no Volume objects; 1: sphere-bounded ones (kernels instantiated with the visit-order rules);
                             // 2: mesh-bounded ones too (those kernels plus the nested mesh walk of Volume::hit)
-    uint32_t *work_counter; // sample-parallel kernel: the next unclaimed block of (tile, group of samples_per_block samples)
-    uint32_t work_blocks;   // blocks of this launch: tiles_launch * ceil(sample_count / samples_per_block)
+    uint32_t *work_counter; // the next unclaimed ticket of the launch (k_render, k_render_bvh: (chunk, tile), chunk-major, one per
+                            // workgroup; sample-parallel kernel: (tile, group of samples_per_block samples), claimed by resident waves)
+    uint32_t work_blocks;   // tickets of this launch: tiles_launch * chunks | tiles_launch * ceil(sample_count / samples_per_block)
     uint32_t samples_per_block;
     uint32_t stack_packed; // 1: a traversal-stack entry is one word -- 4 flag bits, a 16-bit index, 12 bits of entry distance
     uint32_t stack_pad;    //    (trees of at most 65 536 nodes and leaves); 0: a 32-bit ref plus a 16-bit distance
@@ -125,7 +126,7 @@ struct RenderParams {
     // tile sharding
     uint32_t tiles_x, tiles_total, shard, n_shards;
     uint32_t tiles_launch;  // tiles this launch renders (shard, shard + n_shards, ...): grid = tiles_launch * chunks
-    uint32_t chunks;        // pieces every pixel's sample range is cut into (>= 1), chunk-major in blockIdx
+    uint32_t chunks;        // pieces every pixel's sample range is cut into (>= 1); tickets are chunk-major
     uint32_t chunk_taper;   // 0: equal pieces; k in 1..7: lengths fall linearly from (8+k)/8 to (8-k)/8 of the mean
     float *carry_rgba;      // float4 running sums handed from chunk to chunk (chunks > 1)
     float *samples;         // k_render_bvh_sp: float4 [sample - sample_begin][pixel], one clamped radiance per sample

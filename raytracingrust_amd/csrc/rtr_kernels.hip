@@ -454,15 +454,9 @@ RTR_DEV uint32_t stack_pack32(uint32_t ref, float e) {
 }
 RTR_DEV uint32_t stack_ref32(uint32_t w) { return (w & 0xF0000000u) | ((w >> 12) & 0xFFFFu); }
 RTR_DEV float stack_t32(uint32_t w) { return __uint_as_float((w & 0xFFFu) << 19); }
-#ifndef RTR_X_STACK_F32
 typedef uint16_t StackT;
 RTR_DEV StackT stack_t_pack(float e) { return (StackT)(__float_as_uint(e) >> 16); }
 RTR_DEV float stack_t_unpack(StackT h) { return __uint_as_float((uint32_t)h << 16); }
-#else
-typedef float StackT;
-RTR_DEV StackT stack_t_pack(float e) { return e; }
-RTR_DEV float stack_t_unpack(StackT h) { return h; }
-#endif
 
 struct Best {
     float t, u, v;
@@ -574,11 +568,6 @@ __device__ __forceinline__ bool lane_of(uint64_t mask) { return __builtin_amdgcn
 // triangles of a pair in one 96-byte gather, +13 VGPRs and no faster; an explicit bound test on the push, -1 ... -4 %:
 // one push per node record on the path, sp <= tree height < p.stack_cap by construction of the flattener, checked on the
 // host by tests/cpp/scene_sanity.cpp.)
-#ifndef RTR_X_LEAF_NEXT_TRIP
-#define RTR_LEAF_NOW_ (!pop_ && (cur & REF_LEAF))
-#else // round-1 form, for A/B runs: only lanes that stood at a leaf when the trip began test it
-#define RTR_LEAF_NOW_ leaf0_
-#endif
 #define RTR_WALK_TRIP(RAY, TMAX_BOX, ON_EMPTY)                                                                           \
     {                                                                                                                    \
         RTR_LS1(1) RTR_LS(2, true)                                                                                       \
@@ -658,7 +647,7 @@ __device__ __forceinline__ bool lane_of(uint64_t mask) { return __builtin_amdgcn
         /* A lane whose node step has just descended into a leaf tests it in the same trip (and so does a lane that stood */ \
         /* at a leaf when the trip began): a leaf visit costs no trip of its own.  Same operations per lane in the same  */ \
         /* order; 5-6 % fewer wave trips' worth of time on C1 / C3 / C4 (round 2).                                       */ \
-        if (RTR_LEAF_NOW_) {                                                                                             \
+        if (!pop_ && (cur & REF_LEAF)) {                                                                                             \
             RTR_LS1(4) RTR_LS(3, true)                                                                                   \
             /* a REF_PAIR ref stands for Split(leaf L, leaf L+1), its box already tested where the ref was read */       \
             test_leaf<VOL>(p, cur & ~REF_PAIR, RAY, inv, a, best, rng, stk_ref, sp, lane);                               \
@@ -759,7 +748,6 @@ RTR_DEV bool world_hit(const RenderParams &p, const Ray &r, Hit &h, uint32_t *st
         // +10 VGPRs and an LDS fetch per candidate outweigh the skipped root blocks.)
         float closest = __builtin_inff();
         int best = -1;
-#ifndef RTR_X_NO_DEFERRED_DIVISION
         // Deferred division.  Sphere::hit divides each root's numerator n = -half_b -/+ sqrt(disc) by a = |d|^2 only
         // to COMPARE the quotient with tmin and with closest_so_far (objects.rs:38-44); all roots of one ray share
         // the denominator, so the comparisons can be made on the numerators:
@@ -809,9 +797,6 @@ RTR_DEV bool world_hit(const RenderParams &p, const Ray &r, Hit &h, uint32_t *st
                     }
                 }
             }
-#ifdef RTR_X_COUNT_AMB // diagnostic build only: the segment counter counts exact-path repeats instead
-            if (amb) atomicAdd(p.counter, 0x100000000ull);
-#endif
             RTR_LS(25, amb)
             if (!amb) {
                 if (best >= 0) closest = nb / a;
@@ -828,16 +813,6 @@ RTR_DEV bool world_hit(const RenderParams &p, const Ray &r, Hit &h, uint32_t *st
                 }
             }
         }
-#else
-#pragma unroll
-        for (uint32_t i = 0; i < NS; i++) {
-            float t;
-            if (sphere_t(mk(sr.cx[i], sr.cy[i], sr.cz[i]), sr.r2[i], r, a, closest, t)) {
-                closest = t;
-                best = (int)i;
-            }
-        }
-#endif
         if (best < 0) return false;
         RTR_LS(12, true)
         const float4 w = *reinterpret_cast<const float4 *>(lds_spheres + best * 8); // centre, radius
@@ -847,13 +822,11 @@ RTR_DEV bool world_hit(const RenderParams &p, const Ray &r, Hit &h, uint32_t *st
         h.point = add(r.o, scale(r.d, closest));
         const V3 pc = sub(h.point, mk(w.x, w.y, w.z));
         V3 outward;
-#ifndef RTR_X_NO_SHARED_DIV
         // (p - c) / r, objects.rs:46: three quotients over one radius, whose reciprocal was prepared at staging
         const float r1 = __uint_as_float(lds_spheres[best * 8 + 6]);
         if (lds_spheres[best * 8 + 7] != 0u && shared_div_numerators_ok(pc))
             outward = mk(shared_div(pc.x, w.w, r1), shared_div(pc.y, w.w, r1), shared_div(pc.z, w.w, r1));
         else
-#endif
             outward = divs(pc, w.w);
         face_forward(h, r, outward);
         return true;
@@ -929,6 +902,21 @@ RTR_DEV bool world_hit(const RenderParams &p, const Ray &r, Hit &h, uint32_t *st
     }
 }
 
+// The launch parameters as the kernel argument segment holds them (RenderParams is the kernels' only argument: offset 0),
+// behind a pointer the compiler cannot see through.  The per-ticket code of the integrate kernels reads its fields -- ticket
+// counter, frame size, pixel order, carry and output pointers -- through it, so that they are (scalar-)loaded where a
+// ticket begins or ends instead of being kept in scalar registers across the segment loop: that loop already needs the
+// 96-register budget for the sphere constants and the camera, and every value spilled from it comes back as a
+// v_readlane in the loop (+27 of them cost the headline kernel 15 %).
+typedef const __attribute__((address_space(4))) RenderParams *KParams;
+RTR_DEV const RenderParams &field(const RenderParams &p) { return p; }
+RTR_DEV const __attribute__((address_space(4))) RenderParams &field(KParams p) { return *p; }
+RTR_DEV KParams kernarg_params() {
+    KParams k = (KParams)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(k));
+    return k;
+}
+
 // --- shading -----------------------------------------------------------------------------------------
 RTR_DEV bool near_zero(V3 v) { // math.rs:6-9
     const float eps = 1.0e-8f;
@@ -976,7 +964,9 @@ RTR_DEV V3 material_rgb(const RenderParams &p, const uint32_t *lds_mats, uint32_
 }
 
 // SkyMap::sample's texel (backgrounds.rs:84-92, math.rs:24-29): index into the row-major image, row 0 = top
-RTR_DEV unsigned long long sky_texel_index(const RenderParams &p, V3 dir) {
+template <class P> // P: the launch parameters by reference or by kernarg pointer
+RTR_DEV unsigned long long sky_texel_index(const P &pp, V3 dir) {
+    const uint32_t sky_w = field(pp).sky_w, sky_h = field(pp).sky_h;
     V3 d = normalize(dir);
     float sx = poly_acos(-d.y);
     float sy = poly_atan2(-d.z, d.x) + kPi;
@@ -985,36 +975,36 @@ RTR_DEV unsigned long long sky_texel_index(const RenderParams &p, V3 dir) {
     // `(v * W) as usize % W` (backgrounds.rs:88-89).  v and u lie in [0, 1], so the product is below W except when the
     // coordinate is exactly 1: the 64-bit remainder -- a software division, ~150 instructions, twice per escaping path --
     // is taken only then (or for a NaN / out-of-range direction); the value is the same either way.
-    const float fx = v * (float)p.sky_w, fy = u * (float)p.sky_h;
+    const float fx = v * (float)sky_w, fy = u * (float)sky_h;
     uint32_t xi, yi;
-    if (fx >= 0.0f && fx < (float)p.sky_w) xi = (uint32_t)fx; // (uint32_t)fx < W: no remainder to take
-    else xi = (uint32_t)(sat_usize(fx) % p.sky_w);
-    if (fy >= 0.0f && fy < (float)p.sky_h) yi = (uint32_t)fy;
-    else yi = (uint32_t)(sat_usize(fy) % p.sky_h);
-    const unsigned long long x = xi, y = (unsigned long long)p.sky_h - 1ull - yi;
-    return x + y * p.sky_w;
+    if (fx >= 0.0f && fx < (float)sky_w) xi = (uint32_t)fx; // (uint32_t)fx < W: no remainder to take
+    else xi = (uint32_t)(sat_usize(fx) % sky_w);
+    if (fy >= 0.0f && fy < (float)sky_h) yi = (uint32_t)fy;
+    else yi = (uint32_t)(sat_usize(fy) % sky_h);
+    const unsigned long long x = xi, y = (unsigned long long)sky_h - 1ull - yi;
+    return x + y * sky_w;
 }
 // Option "sky_filter" = "bilinear" (SURVEY.md section 8f N2): the four texels around the direction instead of the nearest
 // one -- longitude wraps, latitude clamps at the poles.  An extension, NOT what SkyMap::sample does; the oracle restates the
 // same arithmetic (or_set_sky_filter) so that it can be checked bit for bit.
-RTR_DEV V3 sky_bilinear(const RenderParams &p, V3 dir) {
+RTR_DEV V3 sky_bilinear(KParams p, V3 dir) {
     V3 d = normalize(dir);
     float sx = poly_acos(-d.y);
     float sy = poly_atan2(-d.z, d.x) + kPi;
     float u = sx / kPi;
     float v = sy / (2.0f * kPi);
-    float fx = v * (float)p.sky_w - 0.5f, fy = u * (float)p.sky_h - 0.5f;
+    float fx = v * (float)p->sky_w - 0.5f, fy = u * (float)p->sky_h - 0.5f;
     if (!(fx == fx)) fx = 0.0f;
     if (!(fy == fy)) fy = 0.0f;
     const float x0f = floorf(fx), r0f = floorf(fy);
     const float tx = fx - x0f, ty = fy - r0f;
-    const long long w = (long long)p.sky_w, hh = (long long)p.sky_h;
+    const long long w = (long long)p->sky_w, hh = (long long)p->sky_h;
     long long x0 = (long long)x0f, r0 = (long long)r0f;
     long long x1 = x0 + 1, r1 = r0 + 1;
     x0 = ((x0 % w) + w) % w; x1 = ((x1 % w) + w) % w;
     r0 = r0 < 0 ? 0 : (r0 > hh - 1 ? hh - 1 : r0); r1 = r1 < 0 ? 0 : (r1 > hh - 1 ? hh - 1 : r1);
     const long long y0 = hh - 1 - r0, y1 = hh - 1 - r1;
-    const float4 *sky = reinterpret_cast<const float4 *>(p.sky);
+    const float4 *sky = reinterpret_cast<const float4 *>(p->sky);
     const float4 t00 = sky[x0 + y0 * w], t01 = sky[x1 + y0 * w], t10 = sky[x0 + y1 * w], t11 = sky[x1 + y1 * w];
     const float ux = 1.0f - tx, uy = 1.0f - ty;
     const V3 a = add(scale(mk(t00.x, t00.y, t00.z), ux), scale(mk(t01.x, t01.y, t01.z), tx));
@@ -1025,13 +1015,16 @@ RTR_DEV V3 sky_bilinear(const RenderParams &p, V3 dir) {
 // Background::sample (backgrounds.rs)
 RTR_DEV V3 background(const RenderParams &p, const Ray &r) {
     if (p.bg_kind == 0u) return ld3(p.bg_a); // backgrounds.rs:25-30
+    // (the other kinds read their parameters through the kernarg pointer: loaded where used, not held in scalar registers
+    // across the segment loops of scenes that never come here)
+    const KParams k = kernarg_params();
     if (p.bg_kind == 1u) {                   // backgrounds.rs:44-49, ray.rs:19-26
         float t = 0.5f * (normalize(r.d).y + 1.0f);
-        return add(scale(ld3(p.bg_a), 1.0f - t), scale(ld3(p.bg_b), t));
+        return add(scale(mk(k->bg_a[0], k->bg_a[1], k->bg_a[2]), 1.0f - t), scale(mk(k->bg_b[0], k->bg_b[1], k->bg_b[2]), t));
     }
-    if (p.sky_bilinear) return sky_bilinear(p, r.d); // opt-in (option "sky_filter"), not reference behaviour
+    if (k->sky_bilinear) return sky_bilinear(k, r.d); // opt-in (option "sky_filter"), not reference behaviour
     // backgrounds.rs:84-92, math.rs:24-29: nearest texel of an equirectangular image
-    const float4 texel = reinterpret_cast<const float4 *>(p.sky)[sky_texel_index(p, r.d)];
+    const float4 texel = reinterpret_cast<const float4 *>(k->sky)[sky_texel_index(k, r.d)];
     return mk(texel.x, texel.y, texel.z);
 }
 
@@ -1137,103 +1130,18 @@ RTR_DEV V3 sample_radiance(const RenderParams &p, const uint32_t *lds_mats, Chai
     return clamp_radiance(p, term);
 }
 
-// --- the rejection sampler, wave-cooperative -------------------------------------------------------------------------
-// In the headline kernel the plain loop of sample_unit_ball is the most divergent block there is: 25 of a wave's lanes
-// enter it in an average trip, the wave iterates until its unluckiest lane has an accepted candidate (5.5 times), and
-// 11 lanes are active in an average iteration (scripts/lanestat.py).  All the candidates those lanes need -- 1.9 each --
-// fit into ONE pass of the 64 lanes.  Candidate k of a call is a closed-form function of the call's seed word r and k
-// (the LCG sub-stream, jump-ahead by 3k states), so any lane can evaluate it:
-//   round 0   every lane that needs a sample tests its own candidate 0 (no communication);
-//   round j   the n lanes still without a sample publish their sub-stream state in LDS; lane L evaluates candidate
-//             L / n of requester L % n (each requester gets 64 / n candidates at once, lanes that need nothing
-//             included); an LDS atomic min per requester finds its FIRST accepted candidate, whose lane writes the point
-//             back; a requester left without one advances its state past the candidates tried and goes round again.
-// The accepted point is the one the serial loop would have accepted, bit for bit (same state sequence, same test), and
-// the path's own stream advanced by one word before the first round, as in sample_unit_ball.  Must be called by ALL lanes
-// of the wave (`need` false for lanes that want nothing).  LDS: kCoopWords u32 per wave.
-struct CoopBall {
-    uint32_t *lds; // [list: 64 x (state, first accepted k)][results: 64 x float4][jump: 64 x (A^(3k), C_(3k))]
-};
-constexpr uint32_t kCoopWords = 64u * 2u + 64u * 4u + 64u * 2u;
-RTR_DEV void coop_ball_init(const CoopBall &cb, uint32_t lane) { // jump table: state after 3k steps = s * A3k + C3k
-    uint32_t am = 1u, cm = 0u;
-    for (uint32_t i = 0; i < 3u * lane; i++) { cm = cm * kBallMul + kBallInc; am = am * kBallMul; }
-    cb.lds[64u * 6u + lane * 2u] = am;
-    cb.lds[64u * 6u + lane * 2u + 1u] = cm;
-}
-RTR_DEV V3 coop_ball(const CoopBall &cb, bool need, Rng &rng, uint32_t lane, float &m2) {
-    uint2 *list = reinterpret_cast<uint2 *>(cb.lds);
-    float4 *res = reinterpret_cast<float4 *>(cb.lds + 128u);
-    const uint2 *jump = reinterpret_cast<const uint2 *>(cb.lds + 384u);
-    V3 v = mk(0.0f, 0.0f, 0.0f);
-    m2 = 1.0f;
-    uint32_t s = 0u;
-    bool pending = false;
-    if (need) { // round 0: the lane's own candidate 0
-        s = rng_u32(rng);
-        v.x = ball_coord(s); v.y = ball_coord(s); v.z = ball_coord(s);
-        m2 = dot(v, v);
-        pending = !(m2 <= 1.0f);
-    }
-    const float lane_f = (float)lane + 0.5f;
-    for (;;) {
-        const uint64_t pend = __ballot(pending);
-        if (pend == 0ull) break;
-        const uint32_t n = (uint32_t)__popcll(pend);
-        const uint32_t rho = __builtin_amdgcn_mbcnt_hi((uint32_t)(pend >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pend, 0u));
-        if (pending) list[rho] = make_uint2(s, 0xFFFFFFFFu);
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        // lane L serves requester q = L % n with candidate kk = L / n: (L + 0.5) / n is never within rounding of an integer
-        const float inv_n = __builtin_amdgcn_rcpf((float)n); // 1 ulp is plenty: the quotients below stay 1/128 away from an integer
-        const uint32_t kk = (uint32_t)(lane_f * inv_n);
-        const uint32_t q = lane - kk * n;
-        const uint2 jk = jump[kk];
-        uint32_t t = list[q].x * jk.x + jk.y;
-        V3 c;
-        c.x = ball_coord(t); c.y = ball_coord(t); c.z = ball_coord(t);
-        const float cm2 = dot(c, c);
-        const bool ok = cm2 <= 1.0f;
-        if (ok) atomicMin(&list[q].y, kk);
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        if (ok && list[q].y == kk) res[q] = make_float4(c.x, c.y, c.z, cm2);
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        if (pending) {
-            if (list[rho].y != 0xFFFFFFFFu) {
-                const float4 r = res[rho];
-                v = mk(r.x, r.y, r.z); m2 = r.w;
-                pending = false;
-            } else { // candidates 0 .. K-1 of this round all rejected: K = lanes L with L % n == rho
-                const uint32_t kdone = (uint32_t)((63.5f - (float)rho) * inv_n) + 1u;
-                const uint2 jd = jump[kdone & 63u];
-                s = kdone < 64u ? s * jd.x + jd.y : s; // (kdone == 64: n == 1, handled below)
-                if (kdone >= 64u) { for (uint32_t i = 0; i < 192u; i++) s = s * kBallMul + kBallInc; }
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-    }
-    return v;
-}
-
 // The part of trace_ray (render.rs:38-58) after world.hit: background on a miss, else the material's scatter.
 // Returns `done` (the path ended: `term` is its terminal radiance) or false with the next segment in `ray`.
-// COOP: the wave-cooperative form of the rejection sampler; the function must then be called by every lane of the wave,
-// with `active` false for the lanes that have no segment to shade (they take part in the sampler's rounds only).
-template <bool COOP = false, class Chain>
+template <class Chain>
 RTR_DEV bool shade_segment(const RenderParams &p, bool was_hit, const Hit &h, Ray &ray, Rng &rng, const uint32_t *lds_mats,
-                           Chain &chain, uint32_t lane, uint32_t &depth, V3 &term, bool active = true, const CoopBall *coop = nullptr,
-                           bool *defer_sky = nullptr, const uint32_t *slot_mats = nullptr) {
-    (void)lane; (void)coop;
+                           Chain &chain, uint32_t &depth, V3 &term, bool *defer_sky = nullptr, const uint32_t *slot_mats = nullptr) {
     bool done = false;
     uint32_t kind = 7u, mid = 0u; // 7: no material to scatter from (inactive lane, miss, or a mode that returns at once)
     float param = 0.0f;
     V3 rgb = mk(0.8f, 0.8f, 0.8f);
     float4 mq1 = make_float4(0.0f, 0.0f, 0.0f, 0.0f); // the material record's second half (Dielectric: 1/ir and the two r0^2)
-    RTR_LS(17, active && !was_hit)
-    if (active) {
+    RTR_LS(17, !was_hit)
+    {
         if (!was_hit) {
             // defer_sky: the caller evaluates SkyMap::sample later, from the direction (k_render_bvh_sp -> k_sum_samples)
             if (defer_sky && p.bg_kind == 2u && !p.sky_bilinear) { *defer_sky = true; term = ray.d; }
@@ -1273,12 +1181,7 @@ RTR_DEV bool shade_segment(const RenderParams &p, bool was_hit, const Hit &h, Ra
     RTR_LS(13, kind == 0u) RTR_LS(14, kind == 1u) RTR_LS(15, kind == 2u) RTR_LS(16, kind == 3u)
     const bool need_ball = kind == 0u || kind == 1u || kind == 5u;
     float m2 = 1.0f;
-#ifdef RTR_X_COOP_PLAIN // diagnostic: the cooperative kernel's loop structure with the plain sampler
-    if constexpr (COOP) { if (need_ball) sv = sample_unit_ball(rng, m2); } else
-#endif
-    if constexpr (COOP) {
-        sv = coop_ball(*coop, need_ball, rng, lane, m2);
-    } else if (need_ball) {
+    if (need_ball) {
 #ifdef RTR_X_LANESTAT
         RTR_LS1(20)
         uint32_t bs = rng_u32(rng);
@@ -1316,13 +1219,8 @@ RTR_DEV bool shade_segment(const RenderParams &p, bool was_hit, const Hit &h, Ra
             scattered = false; term = rgb;
         } else if (kind == 3u) { // Dielectric, materials.rs:111-138
             // 1/ir and the two Schlick r0^2 values are constants of the material, divided once on the host
-            // (rtr_scene.cpp) into the record's spare words: re-read here rather than kept live across the sampler
-#ifdef RTR_X_DIELECTRIC_REREAD
-            float4 dq0, dq1;
-            material_load(p, lds_mats, mid, dq0, dq1);
-#else
+            // (rtr_scene.cpp) into the record's spare words
             const float4 dq1 = mq1;
-#endif
             const float ratio = h.front_face ? dq1.y : param;
             const float r0sq = h.front_face ? dq1.z : dq1.w;
             float cos_theta = fminf(dot(h.normal, neg(unit)), 1.0f);
@@ -1337,12 +1235,7 @@ RTR_DEV bool shade_segment(const RenderParams &p, bool was_hit, const Hit &h, Ra
         }
         if (scattered) {
             if (mid != 0xFFFFFFFEu) {
-#ifdef RTR_X_CHAIN_REREAD // (re-reading the colour instead of keeping it live across the sampler)
-                if constexpr (Chain::kStoresRgb) chain.push(mid, material_rgb(p, lds_mats, mid));
-                else chain.push(mid, mk(0.0f, 0.0f, 0.0f));
-#else
                 chain.push(mid, rgb);
-#endif
             }
             ray.o = h.point;
             ray.d = ndir;
@@ -1356,20 +1249,27 @@ RTR_DEV bool shade_segment(const RenderParams &p, bool was_hit, const Hit &h, Ra
     return done;
 }
 
-// Sample chunks.  A launch may cut every pixel's sample range into p.chunks consecutive pieces, one workgroup per
-// (chunk, tile), chunk-major in blockIdx: the tail of the launch then consists of short pieces instead of whole tiles
-// (at 1080p the frame is only ~4 waves' worth of tiles per wave slot, and 11 % of the time was spent with the chip
-// draining).  Chunk c of a tile starts from the running sums chunk c-1 left in p.carry_rgba and adds its samples
-// in the same order, so every pixel sees exactly the additions of the unchunked loop: bit-identical.  The hand-over is
-// a per-tile counter: written with release, read with acquire (agent scope).  A workgroup of chunk c is dispatched a
-// whole chunk's worth of workgroups after its predecessor, so the wait is normally over before it starts.  HIP does not
-// promise dispatch order, so the wait is bounded (seconds of wall time) and a timeout sets the context's fault word:
-// every entry point that synchronises then fails with RTR_ERR_HIP instead of handing out a frame built on stale sums.
+// Tickets and sample chunks.  A launch of k_render / k_render_bvh is one workgroup (one wave) per TICKET; a ticket is
+// (chunk c, group g): the 8x8 tile g of the launch and the c-th of p.chunks consecutive pieces of every pixel's sample
+// range, tickets numbered chunk-major.  A workgroup takes its ticket from a counter in device memory when it starts
+// running -- not from its block index.  Chunk c of a tile starts from the running sums chunk c-1 left in p.carry_rgba and
+// adds its samples in the same order, so every pixel sees exactly the additions of the unchunked loop: bit-identical for
+// any chunk count.  The hand-over is a per-tile counter: written with release, read with acquire (agent scope).
+// Forward progress does not depend on dispatch order (HIP promises none): a workgroup waits only for the ticket (c-1, g),
+// whose number is smaller than its own and which was therefore claimed EARLIER -- by a workgroup that is running or has
+// finished (tickets are claimed by running workgroups only) and that itself waits, if at all, for a still smaller
+// ticket; by induction every claimed ticket completes.  (Round 2 derived the ticket from blockIdx and relied on
+// workgroups being dispatched in index order, with a bounded spin as the net.)  The wait stays bounded in wall time and a
+// timeout sets the context's fault word, as a belt; it cannot fire on a healthy device.
+// Why chunks at all: the tail of the launch then consists of short pieces instead of whole tiles (at 1080p the frame is
+// only ~4.5 tiles per resident wave, and 11 % of the time was spent with the chip draining).
+// Measured and not adopted (round 3, headline frame, all bit-identical): persistent workgroups --
+// one per resident wave, each claiming tickets until none is left -- 15.1-15.3 ms against 14.05: the same instructions
+// and wave-cycles, but 9 % fewer waves resident on average (in-kernel clocks: waves live 14.3 of the launch's 16.2 ms);
+// and groups of 64 pixels sorted by a cost key from a 4-sample pre-pass instead of 8x8 tiles -- 16.9 ms: 6.6 % MORE
+// wave-cycles in the segment loop (neighbouring pixels are the most coherent company a pixel can have) and a longer tail.
 // First sample (relative) of chunk c of n.  With taper k (0..7) the chunk lengths fall linearly from (8+k)/8 of the mean
-// to (8-k)/8: what is left running when the launch has no more workgroups to start are pieces of the LAST chunk, so that
-// one should be the smallest.  1080p headline: equal chunks 16.85 ms, k = 2: 16.6, 4: 16.4, 6: 16.2, 7: 16.0-16.1
-// (halving chunks: 16.9); the tree kernels prefer equal chunks (k = 6: C1 -4 %, C3 -2 %, C4 -6 %), so the launcher
-// sets k = 6 for the sphere world only.
+// to (8-k)/8: what is left running when no tickets remain are pieces of the LAST chunk, so that one should be the smallest.
 RTR_DEV uint32_t chunk_boundary(uint32_t count, uint32_t c, uint32_t n, uint32_t taper) {
     if (taper == 0u || n < 2u) return (uint32_t)((uint64_t)count * c / n);
     // cumulative weight of chunks 0..c-1 with weight_i = 8 + k - 2k*i/(n-1), 8n in total
@@ -1378,49 +1278,166 @@ RTR_DEV uint32_t chunk_boundary(uint32_t count, uint32_t c, uint32_t n, uint32_t
     return (uint32_t)((uint64_t)count * num / (8ull * n * (n - 1u)));
 }
 
-RTR_DEV void chunk_wait(const RenderParams &p, uint32_t tidx, uint32_t chunk) {
-    // Bounded by wall time (s_memrealtime: 100 MHz, independent of the shader clock): a predecessor lives for a
-    // fraction of one launch, the bound is seconds.  Giving up sets bit 0 of the context's sticky fault word, which
-    // every synchronising entry point of the C ABI turns into RTR_ERR_HIP (rtr_api.cpp check_fault).
+RTR_DEV void chunk_wait(KParams p, uint32_t tidx, uint32_t chunk) {
+    // Bounded by wall time (s_memrealtime: 100 MHz, independent of the shader clock).  Giving up sets bit 0 of the
+    // context's sticky fault word, which every synchronising entry point of the C ABI turns into RTR_ERR_HIP
+    // (rtr_api.cpp check_fault).
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-    while (__hip_atomic_load(p.chunk_flags + tidx, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < chunk) {
+    while (__hip_atomic_load(p->chunk_flags + tidx, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < chunk) {
         __builtin_amdgcn_s_sleep(16);
-        if (__builtin_amdgcn_s_memrealtime() - t0 > p.chunk_timeout_ticks) {
-            if (threadIdx.x == 0) atomicOr(p.fault, 1ull);
+        if (__builtin_amdgcn_s_memrealtime() - t0 > p->chunk_timeout_ticks) {
+            if (threadIdx.x == 0) atomicOr(p->fault, 1ull);
             break;
         }
     }
 }
-RTR_DEV void chunk_publish(const RenderParams &p, uint32_t tidx, uint32_t chunk, uint32_t lane) {
+RTR_DEV void chunk_publish(KParams p, uint32_t tidx, uint32_t chunk, uint32_t lane) {
     __threadfence(); // the wave's carry stores are visible device-wide before the counter moves
     __builtin_amdgcn_wave_barrier();
-    if (lane == 0) __hip_atomic_store(p.chunk_flags + tidx, chunk + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    if (lane == 0) __hip_atomic_store(p->chunk_flags + tidx, chunk + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+// The workgroup's ticket (wave-uniform); false when the launch has more workgroups than tickets.  (Only the ticket's number
+// stays live across the segment loop; chunk and tile are divided out of it again where the ticket ends.)
+RTR_DEV void ticket_split(KParams p, uint32_t id, uint32_t &chunk, uint32_t &tidx) {
+    const uint32_t per_chunk = p->tiles_launch;
+    chunk = id / per_chunk;
+    tidx = id - chunk * per_chunk;
+}
+RTR_DEV bool claim_ticket(KParams p, uint32_t lane, uint32_t &id) {
+    id = 0u;
+    if (lane == 0u) id = atomicAdd(p->work_counter, 1u);
+    id = __builtin_amdgcn_readfirstlane(id);
+    return id < p->work_blocks;
 }
 
-// One wave = one 8x8 tile.  LDS (dynamic, 16-byte aligned pieces):
+// calculate_pixel's per-sample head (render.rs:80-90) and Camera::get_ray (camera.rs:19-24): the launch's wave-uniform
+// constants, and the start of sample `si` of the pixel whose stream hash is `hp`.
+struct Primary {
+    V3 o, h, v, llc;
+    SharedDiv div_w, div_h; // (x + xi) / (W - 1), (y + xi') / (H - 1): wave-uniform denominators in [1, 2^31] (else the plain
+    bool uv_fast;           // division), numerators 0 or >= 2^-23 -- inside shared_div's range
+    float wm1, hm1;
+    RTR_DEV void init(const RenderParams &p) {
+        o = ld3(p.cam_origin); h = ld3(p.cam_horizontal); v = ld3(p.cam_vertical); llc = ld3(p.cam_llc);
+        wm1 = p.width_m1; hm1 = p.height_m1;
+        div_w = shared_div_prepare(wm1); div_h = shared_div_prepare(hm1);
+        uv_fast = div_w.ok && div_h.ok;
+    }
+    RTR_DEV void start(uint32_t hp, uint32_t si, float fx, float fy, Rng &rng, Ray &ray) const {
+        rng.state = hash32(hp + si * 0x9E3779B9u);
+        float uu = fx + rng_unit_inclusive(rng); // render.rs:88-89
+        float vv = fy + rng_unit_inclusive(rng);
+        if (uv_fast) {
+            uu = shared_div(uu, div_w.d, div_w.r1);
+            vv = shared_div(vv, div_h.d, div_h.r1);
+        } else {
+            uu = uu / wm1;
+            vv = vv / hm1;
+        }
+        ray.o = o; // camera.rs:19-24
+        ray.d = sub(sub(add(llc, scale(h, uu)), scale(v, vv)), o);
+    }
+};
+
+// render.rs:103-110 for one pixel: sum / spp, then sqrt gamma and RGBA8 (color.rs:34-41); and / or the bare sum (sharded paths)
+RTR_DEV void store_pixel(V3 acc, uint32_t spp, uint32_t pixel, float *sum_rgba, uint8_t *rgba8, float *mean_rgb) {
+    if (sum_rgba) reinterpret_cast<float4 *>(sum_rgba)[pixel] = make_float4(acc.x, acc.y, acc.z, 0.0f);
+    if (rgba8 || mean_rgb) {
+        const float n = (float)spp;
+        const V3 mean = mk(acc.x / n, acc.y / n, acc.z / n);
+        if (mean_rgb) {
+            mean_rgb[3ull * pixel + 0] = mean.x;
+            mean_rgb[3ull * pixel + 1] = mean.y;
+            mean_rgb[3ull * pixel + 2] = mean.z;
+        }
+        if (rgba8) {
+            const uint32_t r8 = sat_u8(sqrtf(mean.x) * 255.0f), g8 = sat_u8(sqrtf(mean.y) * 255.0f), b8 = sat_u8(sqrtf(mean.z) * 255.0f);
+            reinterpret_cast<uint32_t *>(rgba8)[pixel] = r8 | (g8 << 8) | (b8 << 16) | (255u << 24);
+        }
+    }
+}
+// the material table's copy in LDS (one wave per workgroup: the caller's LDS wait is the only barrier needed)
+RTR_DEV void stage_materials(const RenderParams &p, uint32_t *lds_mat_base, uint32_t lane) {
+    for (uint32_t i = lane; i < p.lds_materials * 8u; i += 64u) lds_mat_base[i] = reinterpret_cast<const uint32_t *>(p.materials)[i];
+}
+// one atomic per wave: the ray segments its lanes traced
+RTR_DEV void count_segments(uint32_t nseg, uint32_t lane) {
+    unsigned long long total = nseg;
+    for (int off = 32; off > 0; off >>= 1) total += __shfl_xor(total, off, 64);
+    if (lane == 0 && total) atomicAdd(kernarg_params()->counter, total);
+}
+// A ticket's 64 pixels, one per lane: the 8x8 tile `tidx` of this shard.  render.rs:76-77: index = y * W + x.
+RTR_DEV bool ticket_pixel(KParams p, uint32_t tidx, uint32_t lane, uint32_t &pixel, float &fx, float &fy) {
+    const uint32_t width = p->width;
+    const uint32_t tile = tidx * p->n_shards + p->shard, tiles_x = p->tiles_x;
+    const uint32_t tx = tile % tiles_x, ty = tile / tiles_x;
+    const uint32_t x = tx * 8u + (lane & 7u), y = ty * 8u + (lane >> 3);
+    pixel = y * width + x;
+    fx = (float)x; fy = (float)y;
+    return tile < p->tiles_total && x < width && y < p->height;
+}
+
+// What a lane needs to start its pixel's share of a ticket: the pixel's stream constants, the sample range, the running sum.
+struct TicketLane {
+    uint32_t pixel;                   // 0xFFFFFFFF: the lane has no pixel in this ticket
+    uint32_t hp, inc, s_first, s_end; // s_end: one past the lane's last sample (= s_first for a lane without a pixel)
+    float fx, fy;
+    V3 acc;
+};
+RTR_DEV TicketLane ticket_begin(uint32_t id, uint32_t lane) {
+    const KParams k = kernarg_params();
+    uint32_t chunk, tidx;
+    ticket_split(k, id, chunk, tidx);
+    TicketLane t;
+    const bool inside = ticket_pixel(k, tidx, lane, t.pixel, t.fx, t.fy);
+    // per-pixel stream constants
+    t.hp = hash32(t.pixel ^ k->seed_key0); // the two keys are hashes of the whole 64-bit seed (rtr_api.cpp)
+    t.inc = (hash32(t.hp + k->seed_key1) << 1) | 1u;
+    // samples [sample_begin, sample_begin + sample_count) of this pixel; the random stream is keyed by the
+    // absolute sample index, so a frame split by samples over several launches / GPUs draws the same numbers
+    const uint32_t begin = k->sample_begin, count = k->sample_count, chunks = k->chunks, taper = k->chunk_taper;
+    t.s_first = begin + chunk_boundary(count, chunk, chunks, taper);
+    const uint32_t s_last = begin + chunk_boundary(count, chunk + 1u, chunks, taper);
+    // (per lane on purpose: the wave-uniform form -- lanes off the frame's edge starting at s_last -- saves a register
+    // and measured 0.8 % slower)
+    t.s_end = (inside && k->max_depth > 0u) ? s_last : t.s_first;
+    t.acc = mk(0.0f, 0.0f, 0.0f);
+    if (chunk > 0u) { // continue from the sums the previous chunk of this group left behind
+        chunk_wait(k, tidx, chunk);
+        if (inside) {
+            const float4 c = reinterpret_cast<const float4 *>(k->carry_rgba)[t.pixel];
+            t.acc = mk(c.x, c.y, c.z);
+        }
+    }
+    if (!inside) t.pixel = 0xFFFFFFFFu;
+    return t;
+}
+// ... and to end it: hand the running sum to the next chunk, or finish the pixel
+RTR_DEV void ticket_end(uint32_t id, uint32_t lane, uint32_t pixel, V3 acc) {
+    const KParams k = kernarg_params();
+    uint32_t chunk, tidx;
+    ticket_split(k, id, chunk, tidx);
+    const bool inside = pixel != 0xFFFFFFFFu;
+    if (chunk + 1u < k->chunks) {
+        if (inside) reinterpret_cast<float4 *>(k->carry_rgba)[pixel] = make_float4(acc.x, acc.y, acc.z, 0.0f);
+        chunk_publish(k, tidx, chunk, lane);
+    } else if (inside) {
+        store_pixel(acc, k->spp, pixel, k->sum_rgba, k->rgba8, k->mean_rgb);
+    }
+}
+
+// One lane = one pixel of the workgroup's ticket.  LDS (dynamic, 16-byte aligned pieces):
 //   [chain: max_depth x 64 u32][stack refs: cap x 64][stack t: cap x 64][spheres: NS x 8][materials: lds_mats x 8]
-#ifndef RTR_X_WAVES_PER_EU
-#define RTR_X_WAVES_PER_EU 1
-#endif
 template <uint32_t WORLD, uint32_t NS, uint32_t VOL, bool MESH>
 // 96 scalar registers: a wave's SGPRs come in 16-register granules out of 800 per SIMD, so the 105 the compiler would
 // take (sphere constants + camera + parameters) admit 7 waves per SIMD and 96 admit 8 -- the vector registers (62)
 // already allow 8.  Measured +2.4 % on the headline kernel, neutral on the tree kernels.
-#ifndef RTR_X_RENDER_SGPRS
-#define RTR_X_RENDER_SGPRS 96
-#endif
-__attribute__((amdgpu_num_sgpr(RTR_X_RENDER_SGPRS)))
+__attribute__((amdgpu_num_sgpr(96)))
 // (the sphere world at a 7-wave register budget: the compiler would take 77 VGPRs unasked -- 6 waves, 15.4 ms on the
-// headline frame -- and fits 65 without spilling when told to -- 7 waves, 14.7 ms)
-#ifndef RTR_X_SPHERE_WAVES
-#define RTR_X_SPHERE_WAVES 7 // (8: 64 VGPRs with 51 spilled SGPRs, 14.8 ms; 6: 15.4 ms)
-#endif
-__global__ __launch_bounds__(64, WORLD == WORLD_LINEAR_SPHERES ? RTR_X_SPHERE_WAVES : RTR_X_WAVES_PER_EU) void k_render(const RenderParams p) {
+// headline frame -- and fits 65 without spilling when told to -- 7 waves, 14.7 ms; 8: 64 VGPRs with 51 spilled SGPRs, 14.8 ms)
+__global__ __launch_bounds__(64, WORLD == WORLD_LINEAR_SPHERES ? 7 : 1) void k_render(const RenderParams p) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const uint32_t lane = threadIdx.x;
-    const uint32_t chunk = blockIdx.x / p.tiles_launch, tidx = blockIdx.x - chunk * p.tiles_launch;
-    const uint32_t tile = tidx * p.n_shards + p.shard;
-    if (tile >= p.tiles_total) return;
 #ifdef RTR_X_LANESTAT
     if (lane < 32u) rtr_lsc[lane] = 0u;
     __builtin_amdgcn_s_waitcnt(0);
@@ -1450,8 +1467,7 @@ __global__ __launch_bounds__(64, WORLD == WORLD_LINEAR_SPHERES ? RTR_X_SPHERE_WA
             lds_spheres[lane * 8u + 7u] = sd.ok ? 1u : 0u;
         }
     }
-    if (p.lds_materials)
-        for (uint32_t i = lane; i < p.lds_materials * 8u; i += 64u) lds_mat_base[i] = reinterpret_cast<const uint32_t *>(p.materials)[i];
+    if (p.lds_materials) stage_materials(p, lds_mat_base, lane);
     // sphere world: a copy of each sphere's material record next to the sphere table, addressed by the sphere's slot, so
     // that the record of the hit sphere's material can be fetched together with the sphere's own record
     uint32_t *slot_mats = nullptr;
@@ -1463,71 +1479,9 @@ __global__ __launch_bounds__(64, WORLD == WORLD_LINEAR_SPHERES ? RTR_X_SPHERE_WA
     __builtin_amdgcn_s_waitcnt(0); // vmcnt(0) lgkmcnt(0): the tables are in LDS before any lane reads them
     __builtin_amdgcn_wave_barrier();
 
-    const uint32_t tx = tile % p.tiles_x, ty = tile / p.tiles_x;
-    const uint32_t x = tx * 8u + (lane & 7u), y = ty * 8u + (lane >> 3);
-    const bool inside = x < p.width && y < p.height;
-    const uint32_t pixel = y * p.width + x; // render.rs:76-77: index = y*W + x
-    const float fx = (float)x, fy = (float)y;
-
-    const V3 cam_o = ld3(p.cam_origin), cam_h = ld3(p.cam_horizontal), cam_v = ld3(p.cam_vertical), cam_llc = ld3(p.cam_llc);
-
-    // per-pixel stream constants
-    const uint32_t hp = hash32(pixel ^ p.seed_key0); // the two keys are hashes of the whole 64-bit seed (rtr_api.cpp)
-    Rng rng;
-    rng.inc = (hash32(hp + p.seed_key1) << 1) | 1u;
-    rng.state = 0u;
-
-    V3 acc = mk(0.0f, 0.0f, 0.0f);
+    Primary cam;
+    cam.init(p);
     uint32_t nseg = 0;
-    // samples [sample_begin, sample_begin + sample_count) of this pixel; the random stream is keyed by the
-    // absolute sample index, so a frame split by samples over several launches / GPUs draws the same numbers
-    const uint32_t s_first = p.sample_begin + chunk_boundary(p.sample_count, chunk, p.chunks, p.chunk_taper);
-    const uint32_t s_last = p.sample_begin + chunk_boundary(p.sample_count, chunk + 1u, p.chunks, p.chunk_taper);
-    // (per lane on purpose: the wave-uniform form -- lanes off the frame's edge starting at s_last -- saves a register and
-    // measured 0.8 % slower, 14.21 against 14.11 ms, three alternating runs)
-    const uint32_t spp = (inside && p.max_depth > 0u) ? s_last : s_first;
-    uint32_t s = s_first, depth = 0;
-    if (chunk > 0u) { // continue from the sums the previous chunk of this tile left behind
-        chunk_wait(p, tidx, chunk);
-        if (inside) {
-            const float4 c = reinterpret_cast<const float4 *>(p.carry_rgba)[pixel];
-            acc = mk(c.x, c.y, c.z);
-        }
-    }
-    Ray ray;
-    ray.o = cam_o; ray.d = cam_o;
-
-#ifndef RTR_X_NO_SHARED_DIV
-    // (x + xi) / (W - 1), (y + xi') / (H - 1): wave-uniform denominators in [1, 2^31] (else the plain division),
-    // numerators 0 or >= 2^-23 -- inside shared_div's range
-    const SharedDiv div_w = shared_div_prepare(p.width_m1), div_h = shared_div_prepare(p.height_m1);
-    const bool uv_fast = div_w.ok && div_h.ok;
-#endif
-    auto start_sample = [&](uint32_t si) {
-        rng.state = hash32(hp + si * 0x9E3779B9u);
-        // render.rs:88-89
-        float u = fx + rng_unit_inclusive(rng);
-        float v = fy + rng_unit_inclusive(rng);
-#ifndef RTR_X_NO_SHARED_DIV
-        if (uv_fast) {
-            u = shared_div(u, div_w.d, div_w.r1);
-            v = shared_div(v, div_h.d, div_h.r1);
-        } else
-#endif
-        {
-            u = u / p.width_m1;
-            v = v / p.height_m1;
-        }
-        // camera.rs:19-24
-        ray.o = cam_o;
-        ray.d = sub(sub(add(cam_llc, scale(cam_h, u)), scale(cam_v, v)), cam_o);
-        depth = 0; chain.reset();
-    };
-    if (s < spp) start_sample(s);
-
-#ifdef RTR_X_COUNT_ITERS // diagnostic build only: the segment counter returns wave-iterations*64 instead
-    uint32_t n_iter = 0;
-#endif
 #ifdef RTR_X_STAMPS // diagnostic build only: wave-cycle shares of the loop's sections -> counter ring slots 1..5
     unsigned long long st_acc[5] = {0, 0, 0, 0, 0};
     unsigned long long st_last = __builtin_amdgcn_s_memtime();
@@ -1536,65 +1490,43 @@ __global__ __launch_bounds__(64, WORLD == WORLD_LINEAR_SPHERES ? RTR_X_SPHERE_WA
 #else
 #define RTR_STAMP(k)
 #endif
-    // Measured on the headline frame (1080p, 256 spp; MI355X, round 2), bit-identical frames in every case: plain
-    // loop 15.3 ms; this kernel's every-lane-stays loop with the plain sampler 15.9 ms; with the cooperative sampler
-    // 16.3 ms (70 VGPRs; capped to 64: 16.4 ms).  A round is ~45 vector instructions -- two iterations of the plain loop,
-    // as planned -- but its four dependent LDS round trips and the restructured loop cost more than the 3-4 saved
-    // iterations bring.  Kept for the record behind -DRTR_X_COOP_BALL, not in the product.
-#ifdef RTR_X_COOP_BALL
-    constexpr bool COOP = WORLD == WORLD_LINEAR_SPHERES && NS > 0;
-#else
-    constexpr bool COOP = false;
-#endif
-    if constexpr (COOP) {
-        // Every lane stays in the loop until the wave's last path has ended: the rejection sampler inside shade_segment is
-        // wave-cooperative, and a lane that has run out of samples still evaluates candidates for the others.
-        CoopBall cb;
-        cb.lds = lds_mat_base + p.lds_materials * 8u + NS * 8u;
-        coop_ball_init(cb, lane);
-        __builtin_amdgcn_s_waitcnt(0);
-        __builtin_amdgcn_wave_barrier();
-        for (;;) {
-            const bool alive = s < spp;
-            if (__ballot(alive) == 0ull) break;
+
+    uint32_t ticket;
+    if (claim_ticket(kernarg_params(), lane, ticket)) {
+        const TicketLane tk = ticket_begin(ticket, lane);
+        const uint32_t pixel = tk.pixel, hp = tk.hp, spp = tk.s_end;
+        const float fx = tk.fx, fy = tk.fy;
+        Rng rng;
+        rng.inc = tk.inc;
+        rng.state = 0u;
+        V3 acc = tk.acc;
+        uint32_t s = tk.s_first, depth = 0;
+        Ray ray;
+        ray.o = cam.o; ray.d = cam.o;
+        if (s < spp) { cam.start(hp, s, fx, fy, rng, ray); chain.reset(); }
+
+        while (s < spp) {
+            RTR_STAMP(4)
+            RTR_LS(1, true) RTR_LS1(0)
+            // ---- trace_ray body (render.rs:32-59): one segment ----
             Hit h;
-            bool was_hit = false;
-            if (alive) {
-                nseg++;
-                was_hit = world_hit<WORLD, NS, VOL, MESH>(p, ray, h, stk_ref, stk_t, lane, sr, lds_spheres, rng);
-            }
+            nseg++;
             V3 term;
-            const bool done = shade_segment<true>(p, was_hit, h, ray, rng, lds_mats, chain, lane, depth, term, alive, &cb);
-            if (alive && done) {
+            const bool was_hit = world_hit<WORLD, NS, VOL, MESH>(p, ray, h, stk_ref, stk_t, lane, sr, lds_spheres, rng);
+            RTR_STAMP(0)
+            const bool done = shade_segment(p, was_hit, h, ray, rng, lds_mats, chain, depth, term, nullptr, slot_mats);
+            RTR_STAMP(1)
+            RTR_LS(21, done)
+            if (done) {
+                RTR_LS1(22)
                 acc = add(acc, sample_radiance(p, lds_mats, chain, term)); // render.rs:99
                 s++;
-                if (s < spp) start_sample(s);
+                if (s < spp) { cam.start(hp, s, fx, fy, rng, ray); depth = 0; chain.reset(); }
             }
+            RTR_STAMP(3)
         }
-    } else
-    while (s < spp) {
-        RTR_STAMP(4)
-        RTR_LS(1, true) RTR_LS1(0)
-        // ---- trace_ray body (render.rs:32-59): one segment ----
-        Hit h;
-        nseg++;
-#ifdef RTR_X_COUNT_ITERS
-        n_iter++;
-#endif
-        bool done;
-        V3 term;
-        const bool was_hit = world_hit<WORLD, NS, VOL, MESH>(p, ray, h, stk_ref, stk_t, lane, sr, lds_spheres, rng);
-        RTR_STAMP(0)
-        done = shade_segment(p, was_hit, h, ray, rng, lds_mats, chain, lane, depth, term, true, nullptr, nullptr, slot_mats);
-        RTR_STAMP(1)
-        RTR_LS(21, done)
-        if (done) {
-            RTR_LS1(22)
-            acc = add(acc, sample_radiance(p, lds_mats, chain, term)); // render.rs:99
-            s++;
-            if (s < spp) start_sample(s);
-        }
-        RTR_STAMP(3)
+
+        ticket_end(ticket, lane, pixel, acc);
     }
 #ifdef RTR_X_STAMPS
     if (lane == 0 && p.spp > 1u) // scripts/stamps.py makes 5 one-sample launches first, so slots counter-1..-5 exist
@@ -1606,212 +1538,118 @@ __global__ __launch_bounds__(64, WORLD == WORLD_LINEAR_SPHERES ? RTR_X_SPHERE_WA
     if (lane < 32u && p.spp > 1u) // scripts/lanestat.py makes 32 one-sample launches first, so slots counter-1..-32 exist
         atomicAdd(p.counter - 1 - lane, (unsigned long long)rtr_lsc[lane]);
 #endif
-
-    if (chunk + 1u < p.chunks) {
-        if (inside) reinterpret_cast<float4 *>(p.carry_rgba)[pixel] = make_float4(acc.x, acc.y, acc.z, 0.0f);
-        chunk_publish(p, tidx, chunk, lane);
-    } else if (inside) {
-        if (p.sum_rgba) {
-            reinterpret_cast<float4 *>(p.sum_rgba)[pixel] = make_float4(acc.x, acc.y, acc.z, 0.0f);
-        }
-        if (p.rgba8 || p.mean_rgb) {
-            // render.rs:103-110
-            const float n = (float)p.spp;
-            V3 mean = mk(acc.x / n, acc.y / n, acc.z / n);
-            if (p.mean_rgb) {
-                p.mean_rgb[3ull * pixel + 0] = mean.x;
-                p.mean_rgb[3ull * pixel + 1] = mean.y;
-                p.mean_rgb[3ull * pixel + 2] = mean.z;
-            }
-            if (p.rgba8) {
-                uint32_t r8 = sat_u8(sqrtf(mean.x) * 255.0f), g8 = sat_u8(sqrtf(mean.y) * 255.0f),
-                         b8 = sat_u8(sqrtf(mean.z) * 255.0f);
-                reinterpret_cast<uint32_t *>(p.rgba8)[pixel] = r8 | (g8 << 8) | (b8 << 16) | (255u << 24);
-            }
-        }
-    }
-
-#ifdef RTR_X_COUNT_ITERS
-    {
-        uint32_t m = n_iter;
-        for (int off = 32; off > 0; off >>= 1) { uint32_t o = __shfl_xor(m, off, 64); m = o > m ? o : m; }
-        nseg = m; // every lane reports the wave's trip count: the sum is trips*64
-    }
-#endif
-    // one atomic per wave
-    unsigned long long total = nseg;
-    for (int off = 32; off > 0; off >>= 1) total += __shfl_xor(total, off, 64);
-    if (lane == 0 && total) atomicAdd(p.counter, total);
+    count_segments(nseg, lane);
 }
 
 // ---- WORLD_BVH with a resumable walk -------------------------------------------------------------------------------
 // In k_render a wave leaves world.hit only when its slowest lane has finished its walk: rays that need 10 trips wait
 // for rays that need 60 (C4: 19 % of VALU lane-cycles active).  Here the walk is a per-lane state machine inside the
-// main loop: lanes take traversal trips until no more than 5/8 (RTR_TREE_QUORUM_*) of the wave's live lanes are still
+// main loop: lanes take traversal trips until no more than 5/8 (kQuorumMesh) of the wave's live lanes are still
 // walking, then the lanes whose walk has ended shade, scatter or regenerate together and rejoin with a fresh walk, while
 // the late walkers simply keep their state.  Every lane executes exactly the operations it executes in k_render, in the
 // same order (its random stream included), so the frame is bit-identical; only the interleaving between lanes changes.
-#ifndef RTR_TREE_QUORUM_NUM
-#define RTR_TREE_QUORUM_NUM 5
-#endif
-#ifndef RTR_TREE_QUORUM_NUM_SPHERES
-#define RTR_TREE_QUORUM_NUM_SPHERES 2
-#endif
-#ifndef RTR_TREE_QUORUM_DEN
-#define RTR_TREE_QUORUM_DEN 8
-#endif
-#ifndef RTR_X_WALK_UNROLL
-#define RTR_X_WALK_UNROLL 4
-#endif
-constexpr uint32_t kWalkUnroll = RTR_X_WALK_UNROLL;
-#ifndef RTR_X_BVH_SGPRS
-#define RTR_X_BVH_SGPRS 96
-#endif
-#ifndef RTR_X_BVH_WAVES
-#define RTR_X_BVH_WAVES 6 // 80 VGPRs: the 7-wave budget (72) spills since the cull bound joined the walk's state (C4 +5 %, C3 +11 % at 6)
-#endif
+// Walk while more than 5/8 of the live lanes are walking in mesh scenes, 2/8 in sphere scenes, whose shading rounds are
+// short next to a trip (102 spheres: 0 / 1 / 2 / 3 / 4 eighths 13.8 / 14.3 / 14.4 / 14.1 / 13.9 Grays/s; meshes: 4/8 ... 6/8
+// within 2 %, 5/8 best on house.obj, 4/8 on monkey.obj); kWalkUnroll trips per quorum check: C3 +15 %, C4 +5 % over one
+// (2, 3, 4, 6, 8 measured: flat from 3 on).
+constexpr uint32_t kQuorumMesh = 5u, kQuorumSpheres = 2u, kQuorumDen = 8u;
+constexpr uint32_t kWalkUnroll = 4u;
+
+// The head of world_hit<WORLD_BVH> for a lane that starts a segment: per-ray constants, the root's box.  Returns whether
+// the lane has a walk to take (the state is in cur / sp / best / inv / a).
+RTR_DEV bool begin_walk(const RenderParams &p, const Ray &ray, V3 &inv, float &a, Best &best, uint32_t &cur, uint32_t &sp) {
+    a = dot(ray.d, ray.d);                                        // objects.rs:25, hoisted per ray
+    inv = mk(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z);     // aabb.rs:86,103,120, hoisted per ray
+    best_reset(best);
+    const uint32_t root = p.root_ref;
+    bool go = root != REF_NONE;
+    if (go && (root & (REF_LEAF | REF_PAIR)) != REF_LEAF) {
+        float e;
+        go = slab(p.root_box, p.root_box + 3, ray, inv, __builtin_inff(), e);
+    }
+    cur = root; sp = 0u;
+    return go;
+}
+
+// (80 VGPRs, 6 waves per SIMD: the 7-wave budget (72) spills since the cull bound joined the walk's state -- C4 +5 %, C3 +11 % at 6)
 template <uint32_t VOL, bool MESH>
-__attribute__((amdgpu_num_sgpr(RTR_X_BVH_SGPRS)))
-__global__ __launch_bounds__(64, RTR_X_BVH_WAVES) void k_render_bvh(const RenderParams p) {
+__attribute__((amdgpu_num_sgpr(96)))
+__global__ __launch_bounds__(64, 6) void k_render_bvh(const RenderParams p) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const uint32_t lane = threadIdx.x;
-    const uint32_t chunk = blockIdx.x / p.tiles_launch, tidx = blockIdx.x - chunk * p.tiles_launch;
-    const uint32_t tile = tidx * p.n_shards + p.shard;
-    if (tile >= p.tiles_total) return;
     PackChain chain;
     chain.init(lds, lane, p.chain_bits);
     uint32_t *stk_ref = lds + p.chain_lds * 64u;
     StackT *stk_t = reinterpret_cast<StackT *>(stk_ref + p.stack_cap * 64u);
     uint32_t *lds_mat_base = reinterpret_cast<uint32_t *>(stk_t + p.stack_cap * 64u);
     const uint32_t *lds_mats = p.lds_materials ? lds_mat_base : nullptr;
-    if (p.lds_materials)
-        for (uint32_t i = lane; i < p.lds_materials * 8u; i += 64u) lds_mat_base[i] = reinterpret_cast<const uint32_t *>(p.materials)[i];
+    if (p.lds_materials) stage_materials(p, lds_mat_base, lane);
     __builtin_amdgcn_s_waitcnt(0);
     __builtin_amdgcn_wave_barrier();
-
-    const uint32_t tx = tile % p.tiles_x, ty = tile / p.tiles_x;
-    const uint32_t x = tx * 8u + (lane & 7u), y = ty * 8u + (lane >> 3);
-    const bool inside = x < p.width && y < p.height;
-    const uint32_t pixel = y * p.width + x;
-    const float fx = (float)x, fy = (float)y;
-    const V3 cam_o = ld3(p.cam_origin), cam_h = ld3(p.cam_horizontal), cam_v = ld3(p.cam_vertical), cam_llc = ld3(p.cam_llc);
-    const uint32_t hp = hash32(pixel ^ p.seed_key0); // the two keys are hashes of the whole 64-bit seed (rtr_api.cpp)
-    Rng rng;
-    rng.inc = (hash32(hp + p.seed_key1) << 1) | 1u;
-    rng.state = 0u;
-
-    V3 acc = mk(0.0f, 0.0f, 0.0f);
+    Primary cam;
+    cam.init(p);
     uint32_t nseg = 0;
-    const uint32_t s_first = p.sample_begin + chunk_boundary(p.sample_count, chunk, p.chunks, p.chunk_taper);
-    const uint32_t s_last = p.sample_begin + chunk_boundary(p.sample_count, chunk + 1u, p.chunks, p.chunk_taper);
-    const uint32_t spp = (inside && p.max_depth > 0u) ? s_last : s_first;
-    uint32_t s = s_first, depth = 0;
-    if (chunk > 0u) { // continue from the sums the previous chunk of this tile left behind
-        chunk_wait(p, tidx, chunk);
-        if (inside) {
-            const float4 c = reinterpret_cast<const float4 *>(p.carry_rgba)[pixel];
-            acc = mk(c.x, c.y, c.z);
-        }
-    }
-    Ray ray;
-    ray.o = cam_o; ray.d = cam_o;
-    const SharedDiv div_w = shared_div_prepare(p.width_m1), div_h = shared_div_prepare(p.height_m1);
-    const bool uv_fast = div_w.ok && div_h.ok;
-    auto start_sample = [&](uint32_t si) { // render.rs:80-90, camera.rs:19-24 (as in k_render)
-        rng.state = hash32(hp + si * 0x9E3779B9u);
-        float u = fx + rng_unit_inclusive(rng);
-        float v = fy + rng_unit_inclusive(rng);
-        if (uv_fast) {
-            u = shared_div(u, div_w.d, div_w.r1);
-            v = shared_div(v, div_h.d, div_h.r1);
-        } else {
-            u = u / p.width_m1;
-            v = v / p.height_m1;
-        }
-        ray.o = cam_o;
-        ray.d = sub(sub(add(cam_llc, scale(cam_h, u)), scale(cam_v, v)), cam_o);
-        depth = 0; chain.reset();
-    };
-
-    // the walk's per-lane state (world_hit + traverse of k_render, unrolled into the loop below)
-    uint32_t cur = REF_NONE, sp = 0;
-    Best best;
-    best_reset(best);
-    V3 inv = mk(0.0f, 0.0f, 0.0f);
-    float a = 0.0f;
-    bool walking = false;
-    auto begin_segment = [&]() { // the head of world_hit<WORLD_BVH>
-        nseg++;
-        a = dot(ray.d, ray.d);
-        inv = mk(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z);
-        best_reset(best);
-        const uint32_t root = p.root_ref;
-        bool go = root != REF_NONE;
-        if (go && (root & (REF_LEAF | REF_PAIR)) != REF_LEAF) {
-            float e;
-            go = slab(p.root_box, p.root_box + 3, ray, inv, __builtin_inff(), e);
-        }
-        cur = root; sp = 0;
-        walking = go;
-    };
-    bool alive = s < spp;
-    if (alive) { start_sample(s); begin_segment(); }
-
     constexpr bool stack_packed = false;
-    for (;;) {
-        const uint64_t alive_mask = __ballot(alive);
-        if (alive_mask == 0ull) break;
-        const uint32_t quorum = (uint32_t)__popcll(alive_mask) * RTR_TREE_QUORUM_NUM / RTR_TREE_QUORUM_DEN;
-        // ---- walk: one trip per iteration for every lane still walking ----
-        // (RTR_WALK_TRIP: the one trip body every walk expands in place.)
-        while ((uint32_t)__popcll(__ballot(walking)) > quorum) {
-            // (Taking only the kind of step -- node or leaf -- that more walkers wait for was measured 0 ... -10 %:
-            // with both bodies in one trip their gathers overlap.)
-            // kWalkUnroll trips per quorum check: C3 +15 %, C4 +5 % over one (2, 3, 4, 6, 8 measured: flat from 3 on)
-#pragma unroll
-            for (uint32_t rep = 0; rep < kWalkUnroll; rep++)
-            if (walking) RTR_WALK_TRIP(ray, __builtin_inff(), walking = false)
-        }
-        // ---- the lanes whose walk has ended: the rest of trace_ray, then the next segment or the next sample ----
-        if (alive && !walking) {
-            Hit h;
-            const bool was_hit = best.leaf != REF_NONE;
-            if (was_hit) finish_leaf<VOL>(p, best, ray, h);
-            V3 term;
-            const bool done = shade_segment(p, was_hit, h, ray, rng, lds_mats, chain, lane, depth, term);
-            if (done) {
-                acc = add(acc, sample_radiance(p, lds_mats, chain, term)); // render.rs:99
-                s++;
-                if (s < spp) start_sample(s);
-                else alive = false;
-            }
-            if (alive) begin_segment();
-        }
-    }
 
-    if (chunk + 1u < p.chunks) {
-        if (inside) reinterpret_cast<float4 *>(p.carry_rgba)[pixel] = make_float4(acc.x, acc.y, acc.z, 0.0f);
-        chunk_publish(p, tidx, chunk, lane);
-    } else if (inside) {
-        if (p.sum_rgba) reinterpret_cast<float4 *>(p.sum_rgba)[pixel] = make_float4(acc.x, acc.y, acc.z, 0.0f);
-        if (p.rgba8 || p.mean_rgb) { // render.rs:103-110
-            const float n = (float)p.spp;
-            V3 mean = mk(acc.x / n, acc.y / n, acc.z / n);
-            if (p.mean_rgb) {
-                p.mean_rgb[3ull * pixel + 0] = mean.x;
-                p.mean_rgb[3ull * pixel + 1] = mean.y;
-                p.mean_rgb[3ull * pixel + 2] = mean.z;
+    uint32_t ticket;
+    if (claim_ticket(kernarg_params(), lane, ticket)) { // tickets, chunks and their hand-over: as in k_render
+        const TicketLane tk = ticket_begin(ticket, lane);
+        const uint32_t pixel = tk.pixel, hp = tk.hp, spp = tk.s_end;
+        const float fx = tk.fx, fy = tk.fy;
+        Rng rng;
+        rng.inc = tk.inc;
+        rng.state = 0u;
+        V3 acc = tk.acc;
+        uint32_t s = tk.s_first, depth = 0;
+        Ray ray;
+        ray.o = cam.o; ray.d = cam.o;
+        // the walk's per-lane state (world_hit + traverse of k_render, unrolled into the loop below)
+        uint32_t cur = REF_NONE, sp = 0;
+        Best best;
+        best_reset(best);
+        V3 inv = mk(0.0f, 0.0f, 0.0f);
+        float a = 0.0f;
+        bool walking = false;
+        bool alive = s < spp;
+        if (alive) {
+            cam.start(hp, s, fx, fy, rng, ray); chain.reset();
+            nseg++;
+            walking = begin_walk(p, ray, inv, a, best, cur, sp);
+        }
+        for (;;) {
+            const uint64_t alive_mask = __ballot(alive);
+            if (alive_mask == 0ull) break;
+            const uint32_t quorum = (uint32_t)__popcll(alive_mask) * kQuorumMesh / kQuorumDen;
+            // ---- walk: one trip per iteration for every lane still walking (RTR_WALK_TRIP: the one trip body) ----
+            // (Taking only the kind of step -- node or leaf -- that more walkers wait for was measured 0 ... -10 %: with both
+            // bodies in one trip their gathers overlap.)
+            while ((uint32_t)__popcll(__ballot(walking)) > quorum) {
+#pragma unroll
+                for (uint32_t rep = 0; rep < kWalkUnroll; rep++)
+                    if (walking) RTR_WALK_TRIP(ray, __builtin_inff(), walking = false)
             }
-            if (p.rgba8) {
-                uint32_t r8 = sat_u8(sqrtf(mean.x) * 255.0f), g8 = sat_u8(sqrtf(mean.y) * 255.0f),
-                         b8 = sat_u8(sqrtf(mean.z) * 255.0f);
-                reinterpret_cast<uint32_t *>(p.rgba8)[pixel] = r8 | (g8 << 8) | (b8 << 16) | (255u << 24);
+            // ---- the lanes whose walk has ended: the rest of trace_ray, then the next segment or the next sample ----
+            if (alive && !walking) {
+                Hit h;
+                const bool was_hit = best.leaf != REF_NONE;
+                if (was_hit) finish_leaf<VOL>(p, best, ray, h);
+                V3 term;
+                const bool done = shade_segment(p, was_hit, h, ray, rng, lds_mats, chain, depth, term);
+                if (done) {
+                    acc = add(acc, sample_radiance(p, lds_mats, chain, term)); // render.rs:99
+                    s++;
+                    if (s < spp) { cam.start(hp, s, fx, fy, rng, ray); depth = 0; chain.reset(); }
+                    else alive = false;
+                }
+                if (alive) {
+                    nseg++;
+                    walking = begin_walk(p, ray, inv, a, best, cur, sp);
+                }
             }
         }
+        ticket_end(ticket, lane, pixel, acc);
     }
-    unsigned long long total = nseg;
-    for (int off = 32; off > 0; off >>= 1) total += __shfl_xor(total, off, 64);
-    if (lane == 0 && total) atomicAdd(p.counter, total);
+    count_segments(nseg, lane);
 }
 
 // ---- WORLD_BVH, samples instead of pixels ------------------------------------------------------------------------
@@ -1826,10 +1664,7 @@ __global__ __launch_bounds__(64, RTR_X_BVH_WAVES) void k_render_bvh(const Render
 // volume kernels, which would spill 8 ... 25.
 template <uint32_t VOL, bool MESH, bool PACKED>
 __attribute__((amdgpu_num_sgpr(128)))
-#ifndef RTR_X_SP_WAVES
-#define RTR_X_SP_WAVES (VOL == 0u ? 7 : 6)
-#endif
-__global__ __launch_bounds__(64, RTR_X_SP_WAVES) void k_render_bvh_sp(const RenderParams p) {
+__global__ __launch_bounds__(64, VOL == 0u ? 7 : 6) void k_render_bvh_sp(const RenderParams p) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const uint32_t lane = threadIdx.x;
 #ifdef RTR_X_LANESTAT
@@ -1843,8 +1678,7 @@ __global__ __launch_bounds__(64, RTR_X_SP_WAVES) void k_render_bvh_sp(const Rend
     StackT *stk_t = reinterpret_cast<StackT *>(stk_ref + p.stack_cap * 64u);
     uint32_t *lds_mat_base = PACKED ? stk_ref + p.stack_cap * 64u : reinterpret_cast<uint32_t *>(stk_t + p.stack_cap * 64u);
     const uint32_t *lds_mats = p.lds_materials ? lds_mat_base : nullptr;
-    if (p.lds_materials)
-        for (uint32_t i = lane; i < p.lds_materials * 8u; i += 64u) lds_mat_base[i] = reinterpret_cast<const uint32_t *>(p.materials)[i];
+    if (p.lds_materials) stage_materials(p, lds_mat_base, lane);
     __builtin_amdgcn_s_waitcnt(0);
     __builtin_amdgcn_wave_barrier();
 
@@ -1855,7 +1689,8 @@ __global__ __launch_bounds__(64, RTR_X_SP_WAVES) void k_render_bvh_sp(const Rend
     // word sustains).  With a fixed share per wave (round 2's first form: tile x sample range) every one of ~550 000
     // waves paid its own set-up and its own ragged end; now those are paid once per resident wave.
     uint32_t tx = 0u, ty = 0u;                         // the current block's tile (wave-uniform)
-    const V3 cam_o = ld3(p.cam_origin), cam_h = ld3(p.cam_horizontal), cam_v = ld3(p.cam_vertical), cam_llc = ld3(p.cam_llc);
+    Primary cam;
+    cam.init(p);
     // the lane's current work item: one sample of one pixel of a tile
     uint32_t hp = 0;
     float fx = 0.0f, fy = 0.0f;
@@ -1867,24 +1702,7 @@ __global__ __launch_bounds__(64, RTR_X_SP_WAVES) void k_render_bvh_sp(const Rend
     bool pool_empty = false;                             // (all wave-uniform)
     uint32_t depth = 0;
     Ray ray;
-    ray.o = cam_o; ray.d = cam_o;
-    const SharedDiv div_w = shared_div_prepare(p.width_m1), div_h = shared_div_prepare(p.height_m1);
-    const bool uv_fast = div_w.ok && div_h.ok;
-    auto start_sample = [&](uint32_t si) { // render.rs:80-90, camera.rs:19-24 (as in k_render)
-        rng.state = hash32(hp + si * 0x9E3779B9u);
-        float u = fx + rng_unit_inclusive(rng);
-        float v = fy + rng_unit_inclusive(rng);
-        if (uv_fast) {
-            u = shared_div(u, div_w.d, div_w.r1);
-            v = shared_div(v, div_h.d, div_h.r1);
-        } else {
-            u = u / p.width_m1;
-            v = v / p.height_m1;
-        }
-        ray.o = cam_o;
-        ray.d = sub(sub(add(cam_llc, scale(cam_h, u)), scale(cam_v, v)), cam_o);
-        depth = 0; chain.reset();
-    };
+    ray.o = cam.o; ray.d = cam.o;
 
     // the walk's per-lane state (world_hit + traverse of k_render, unrolled into the loop below)
     uint32_t cur = REF_NONE, sp = 0;
@@ -1897,20 +1715,7 @@ __global__ __launch_bounds__(64, RTR_X_SP_WAVES) void k_render_bvh_sp(const Rend
     // on every trip.
     uint64_t walking_m = 0ull;
     constexpr bool stack_packed = PACKED; // one-word stack entries (RenderParams::stack_packed, set for small trees)
-    auto begin_segment = [&]() -> bool { // the head of world_hit<WORLD_BVH>; true = the lane has a walk to take
-        nseg++;
-        a = dot(ray.d, ray.d);
-        inv = mk(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z);
-        best_reset(best);
-        const uint32_t root = p.root_ref;
-        bool go = root != REF_NONE;
-        if (go && (root & (REF_LEAF | REF_PAIR)) != REF_LEAF) {
-            float e;
-            go = slab(p.root_box, p.root_box + 3, ray, inv, __builtin_inff(), e);
-        }
-        cur = root; sp = 0;
-        return go;
-    };
+    auto begin_segment = [&]() -> bool { nseg++; return begin_walk(p, ray, inv, a, best, cur, sp); }; // true = the lane has a walk to take
     uint64_t alive_m = 0ull;
     uint64_t need_m = wave_mask(true); // the lanes that want the workgroup's next (sample, pixel) pair
     const uint32_t n_pixels = p.width * p.height;
@@ -1919,15 +1724,17 @@ __global__ __launch_bounds__(64, RTR_X_SP_WAVES) void k_render_bvh_sp(const Rend
         while (need_m != 0ull) {
             if (next_item >= n_items) { // the block is used up: claim the next one (wave-uniform)
                 if (pool_empty) { need_m = 0ull; break; } // nothing is left: the asking lanes retire
+                const KParams k = kernarg_params(); // (the block's parameters are loaded here, not held across the walk)
                 uint32_t id = 0u;
-                if (lane == 0u) id = atomicAdd(p.work_counter, 1u);
+                if (lane == 0u) id = atomicAdd(k->work_counter, 1u);
                 id = __builtin_amdgcn_readfirstlane(id);
-                if (id >= p.work_blocks) { pool_empty = true; need_m = 0ull; break; }
-                const uint32_t group = id / p.tiles_launch, tile = (id - group * p.tiles_launch) * p.n_shards + p.shard;
-                tx = tile % p.tiles_x; ty = tile / p.tiles_x;
-                const uint32_t s0 = group * p.samples_per_block;
-                s_first = p.sample_begin + s0;
-                n_items = 64u * (p.sample_count - s0 < p.samples_per_block ? p.sample_count - s0 : p.samples_per_block);
+                if (id >= k->work_blocks) { pool_empty = true; need_m = 0ull; break; }
+                const uint32_t per_group = k->tiles_launch, tiles_x = k->tiles_x, per_block = k->samples_per_block, count = k->sample_count;
+                const uint32_t group = id / per_group, tile = (id - group * per_group) * k->n_shards + k->shard;
+                tx = tile % tiles_x; ty = tile / tiles_x;
+                const uint32_t s0 = group * per_block;
+                s_first = k->sample_begin + s0;
+                n_items = 64u * (count - s0 < per_block ? count - s0 : per_block);
                 next_item = 0u;
             }
             const uint64_t asking = need_m;
@@ -1948,7 +1755,7 @@ __global__ __launch_bounds__(64, RTR_X_SP_WAVES) void k_render_bvh_sp(const Rend
                         rng.inc = (hash32(hp + p.seed_key1) << 1) | 1u;
                         slot = (si - p.sample_begin) * n_pixels + pixel;
                         got = true;
-                        start_sample(si);
+                        cam.start(hp, si, fx, fy, rng, ray); depth = 0; chain.reset(); // render.rs:80-90, camera.rs:19-24
                         began = begin_segment();
                     } else {
                         again = true; // off the ragged edge: ask again
@@ -1964,17 +1771,11 @@ __global__ __launch_bounds__(64, RTR_X_SP_WAVES) void k_render_bvh_sp(const Rend
 
     for (;;) {
         if (alive_m == 0ull) break;
-        // walk while more than 5/8 of the live lanes are walking in mesh scenes, 2/8 in sphere scenes, whose shading rounds
-        // are short next to a trip (102 spheres: 0 / 1 / 2 / 3 / 4 eighths 13.8 / 14.3 / 14.4 / 14.1 / 13.9 Grays/s;
-        // meshes: 4/8 ... 6/8 within 2 %, 5/8 best on house.obj, 4/8 on monkey.obj)
-        const uint32_t quorum = (uint32_t)__popcll(alive_m) * (MESH ? RTR_TREE_QUORUM_NUM : RTR_TREE_QUORUM_NUM_SPHERES) / RTR_TREE_QUORUM_DEN;
+        const uint32_t quorum = (uint32_t)__popcll(alive_m) * (MESH ? kQuorumMesh : kQuorumSpheres) / kQuorumDen; // (see k_render_bvh)
         RTR_LS1(0) RTR_LS(15, lane_of(alive_m))
         // ---- walk: one trip per iteration for every lane still walking ----
         // (RTR_WALK_TRIP: the one trip body every walk expands in place.)
         while ((uint32_t)__popcll(walking_m) > quorum) {
-            // (Taking only the kind of step -- node or leaf -- that more walkers wait for was measured 0 ... -10 %:
-            // with both bodies in one trip their gathers overlap.)
-            // kWalkUnroll trips per quorum check: C3 +15 %, C4 +5 % over one (2, 3, 4, 6, 8 measured: flat from 3 on)
 #pragma unroll
             for (uint32_t rep = 0; rep < kWalkUnroll; rep++) {
                 bool ended = false;
@@ -1991,7 +1792,7 @@ __global__ __launch_bounds__(64, RTR_X_SP_WAVES) void k_render_bvh_sp(const Rend
             if (was_hit) finish_leaf<VOL>(p, best, ray, h);
             V3 term;
             bool sky = false;
-            const bool done = shade_segment(p, was_hit, h, ray, rng, lds_mats, chain, lane, depth, term, true, nullptr, &sky);
+            const bool done = shade_segment(p, was_hit, h, ray, rng, lds_mats, chain, depth, term, &sky);
             if (done) { // the sample's clamped radiance (render.rs:95-97) goes to memory; k_sum_samples adds them in order
                 // A path that escapes to a SkyMap leaves its DIRECTION and its attenuation chain instead (up to 3 material
                 // ids below 256, packed into the fourth word): k_sum_samples, whose lanes are all busy, does the
@@ -2029,9 +1830,7 @@ __global__ __launch_bounds__(64, RTR_X_SP_WAVES) void k_render_bvh_sp(const Rend
     __builtin_amdgcn_wave_barrier();
     if (lane < 32u && p.spp > 1u) atomicAdd(p.counter - 1 - lane, (unsigned long long)rtr_lsc[lane]);
 #endif
-    unsigned long long total = nseg;
-    for (int off = 32; off > 0; off >>= 1) total += __shfl_xor(total, off, 64);
-    if (lane == 0 && total) atomicAdd(p.counter, total);
+    count_segments(nseg, lane);
 }
 
 
@@ -2089,26 +1888,21 @@ __global__ __launch_bounds__(64) void k_wf_generate(const RenderParams p) {
     const uint32_t hp = hash32(pixel ^ p.seed_key0);
     Rng rng;
     rng.inc = (hash32(hp + p.seed_key1) << 1) | 1u;
-    rng.state = hash32(hp + (p.sample_begin + s_rel) * 0x9E3779B9u);
-    float u = (float)x + rng_unit_inclusive(rng); // render.rs:88-89
-    float v = (float)y + rng_unit_inclusive(rng);
-    u = u / p.width_m1;
-    v = v / p.height_m1;
-    const V3 cam_o = ld3(p.cam_origin), cam_h = ld3(p.cam_horizontal), cam_v = ld3(p.cam_vertical), cam_llc = ld3(p.cam_llc);
-    const V3 d = sub(sub(add(cam_llc, scale(cam_h, u)), scale(cam_v, v)), cam_o); // camera.rs:19-24
+    rng.state = 0u;
+    Primary cam;
+    cam.init(p);
+    Ray r;
+    cam.start(hp, p.sample_begin + s_rel, (float)x, (float)y, rng, r); // render.rs:80-90, camera.rs:19-24
     float4 *ray = reinterpret_cast<float4 *>(p.wf_ray) + 2ull * id;
-    ray[0] = make_float4(cam_o.x, cam_o.y, cam_o.z, d.x);
-    ray[1] = make_float4(d.y, d.z, 0.0f, 0.0f);
+    ray[0] = make_float4(r.o.x, r.o.y, r.o.z, r.d.x);
+    ray[1] = make_float4(r.d.y, r.d.z, 0.0f, 0.0f);
     reinterpret_cast<uint4 *>(p.wf_state)[id] = make_uint4(rng.state, rng.inc, 0u, s_rel * (p.width * p.height) + pixel);
     p.wf_stage[id] = 0u;
 }
 
 // world.hit (render.rs:38) for every path waiting at depth p.wf_depth.  LDS: [stack refs: cap x 64][stack t: cap x 64][ring]
-#ifndef RTR_X_WF_WAVES
-#define RTR_X_WF_WAVES 6
-#endif
 template <uint32_t VOL, bool MESH>
-__global__ __launch_bounds__(64, RTR_X_WF_WAVES) void k_wf_intersect(const RenderParams p) {
+__global__ __launch_bounds__(64, 6) void k_wf_intersect(const RenderParams p) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const uint32_t lane = threadIdx.x;
     uint32_t *stk_ref = lds;
@@ -2148,20 +1942,9 @@ __global__ __launch_bounds__(64, RTR_X_WF_WAVES) void k_wf_intersect(const Rende
                         const uint2 rs = *reinterpret_cast<const uint2 *>(p.wf_state + 4ull * id);
                         rng.state = rs.x; rng.inc = rs.y;
                     }
-                    // the head of world_hit<WORLD_BVH>
                     nseg++;
-                    a = dot(ray.d, ray.d);
-                    inv = mk(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z);
-                    best_reset(best);
-                    const uint32_t root = p.root_ref;
-                    bool go = root != REF_NONE;
-                    if (go && (root & (REF_LEAF | REF_PAIR)) != REF_LEAF) {
-                        float e;
-                        go = slab(p.root_box, p.root_box + 3, ray, inv, __builtin_inff(), e);
-                    }
-                    cur = root; sp = 0u;
-                    walking = go;
-                    holding = !go;
+                    walking = begin_walk(p, ray, inv, a, best, cur, sp); // the head of world_hit<WORLD_BVH>
+                    holding = !walking;
                 }
                 sc.tail += want < have ? want : have;
             }
@@ -2185,9 +1968,7 @@ __global__ __launch_bounds__(64, RTR_X_WF_WAVES) void k_wf_intersect(const Rende
             }
         }
     }
-    unsigned long long total = nseg;
-    for (int off = 32; off > 0; off >>= 1) total += __shfl_xor(total, off, 64);
-    if (lane == 0 && total) atomicAdd(p.counter, total);
+    count_segments(nseg, lane);
 }
 
 // The rest of trace_ray (render.rs:39-58) for every path waiting at depth p.wf_depth, full waves of them at a time.
@@ -2199,8 +1980,7 @@ __global__ __launch_bounds__(64) void k_wf_shade(const RenderParams p) {
     uint32_t *ring = lds;
     uint32_t *lds_mat_base = lds + kWfRing;
     const uint32_t *lds_mats = p.lds_materials ? lds_mat_base : nullptr;
-    if (p.lds_materials)
-        for (uint32_t i = lane; i < p.lds_materials * 8u; i += 64u) lds_mat_base[i] = reinterpret_cast<const uint32_t *>(p.materials)[i];
+    if (p.lds_materials) stage_materials(p, lds_mat_base, lane);
     __builtin_amdgcn_s_waitcnt(0);
     __builtin_amdgcn_wave_barrier();
     const uint32_t depth0 = p.wf_depth;
@@ -2230,7 +2010,7 @@ __global__ __launch_bounds__(64) void k_wf_shade(const RenderParams p) {
             const bool was_hit = best.leaf != REF_NONE;
             if (was_hit) finish_leaf<VOL>(p, best, ray, h);
             V3 term;
-            const bool done = shade_segment(p, was_hit, h, ray, rng, lds_mats, chain, lane, depth, term);
+            const bool done = shade_segment(p, was_hit, h, ray, rng, lds_mats, chain, depth, term);
             if (done) { // the sample's clamped radiance (render.rs:95-97); k_sum_samples adds a pixel's samples in order
                 const V3 rad = sample_radiance(p, lds_mats, chain, term);
                 reinterpret_cast<float4 *>(p.samples)[st.w] = make_float4(rad.x, rad.y, rad.z, 0.0f);
@@ -2301,20 +2081,7 @@ __global__ __launch_bounds__(256) void k_sum_samples(const RenderParams p, const
         reinterpret_cast<float4 *>(acc_io)[i] = make_float4(acc.x, acc.y, acc.z, 0.0f);
         return;
     }
-    if (sum_rgba) reinterpret_cast<float4 *>(sum_rgba)[i] = make_float4(acc.x, acc.y, acc.z, 0.0f);
-    if (rgba8 || mean_rgb) {
-        const float n = (float)spp;
-        V3 mean = mk(acc.x / n, acc.y / n, acc.z / n);
-        if (mean_rgb) {
-            mean_rgb[3ull * i + 0] = mean.x;
-            mean_rgb[3ull * i + 1] = mean.y;
-            mean_rgb[3ull * i + 2] = mean.z;
-        }
-        if (rgba8) {
-            uint32_t r8 = sat_u8(sqrtf(mean.x) * 255.0f), g8 = sat_u8(sqrtf(mean.y) * 255.0f), b8 = sat_u8(sqrtf(mean.z) * 255.0f);
-            reinterpret_cast<uint32_t *>(rgba8)[i] = r8 | (g8 << 8) | (b8 << 16) | (255u << 24);
-        }
-    }
+    store_pixel(acc, spp, i, sum_rgba, rgba8, mean_rgb);
 }
 
 // render.rs:103-110 for the sharded path: sum -> mean -> sqrt -> RGBA8
@@ -2322,18 +2089,8 @@ __global__ __launch_bounds__(256) void k_resolve(const float *sum_rgba, uint32_t
                                                  float *mean_rgb) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_pixels) return;
-    float4 s = reinterpret_cast<const float4 *>(sum_rgba)[i];
-    const float n = (float)spp;
-    float r = s.x / n, g = s.y / n, b = s.z / n;
-    if (mean_rgb) {
-        mean_rgb[3ull * i + 0] = r;
-        mean_rgb[3ull * i + 1] = g;
-        mean_rgb[3ull * i + 2] = b;
-    }
-    if (rgba8) {
-        uint32_t r8 = sat_u8(sqrtf(r) * 255.0f), g8 = sat_u8(sqrtf(g) * 255.0f), b8 = sat_u8(sqrtf(b) * 255.0f);
-        reinterpret_cast<uint32_t *>(rgba8)[i] = r8 | (g8 << 8) | (b8 << 16) | (255u << 24);
-    }
+    const float4 s = reinterpret_cast<const float4 *>(sum_rgba)[i];
+    store_pixel(mk(s.x, s.y, s.z), spp, i, nullptr, rgba8, mean_rgb);
 }
 
 // rtr_probe_hits: world.hit (render.rs:38: tmin = 0.00001, tmax = +inf) for caller-supplied rays, one lane per ray, through
@@ -2482,7 +2239,9 @@ static hipError_t launch_params_kernel(const void *fn, const RenderParams &p, di
 }
 
 hipError_t launch_render(const RenderParams &p, uint32_t grid, uint32_t lds_bytes, hipStream_t stream) {
-    return launch_params_kernel(render_kernel(p), p, dim3(grid), lds_bytes, stream);
+    const void *fn = render_kernel(p);
+    if (!fn) return hipErrorInvalidDeviceFunction;
+    return launch_params_kernel(fn, p, dim3(grid), lds_bytes, stream);
 }
 
 hipError_t launch_wf_generate(const RenderParams &p, uint32_t batch_samples, hipStream_t stream) {
@@ -2491,8 +2250,6 @@ hipError_t launch_wf_generate(const RenderParams &p, uint32_t batch_samples, hip
 }
 uint32_t stack_entry_bytes(const RenderParams &p) { return p.stack_packed ? 4u : 4u + (uint32_t)sizeof(StackT); }
 uint32_t wf_intersect_lds_bytes(const RenderParams &p) { return p.stack_cap * 64u * stack_entry_bytes(p) + kWfRing * 4u; }
-uint32_t coop_ball_lds_bytes() { return kCoopWords * 4u; }
-// (the coop experiment's scratch, when built in, follows the sphere world's slot-material table)
 uint32_t wf_shade_lds_bytes(const RenderParams &p) { return (kWfRing + p.lds_materials * 8u) * 4u; }
 static uint32_t resident_waves(const void *fn, uint32_t lds_bytes) {
     int per_cu = 0, dev = 0, cus = 0;

@@ -3,7 +3,7 @@
 // The reference builds every mesh tree on the CPU by recursive median split with a stable sort per level
 // (lib/core/bvh.rs:59-144, O(n log^2 n), rebuilt by Mesh::build_bvh, mesh.rs:119-121).  This is the GPU alternative for
 // large or changing meshes: a linear BVH over the SAME per-triangle boxes (mesh.rs:201-213, computed by the host
-// flattener in O(n)) -- Morton codes of the box centroids, one radix sort, Karras' parallel radix-tree construction
+// flattener in O(n)) -- Morton codes of the box centroids, one radix sort (rocPRIM, rtr_sort.hip), Karras' parallel radix-tree construction
 // (one thread per inner node), and one bottom-up pass that unions the boxes, measures the height and writes the 64-byte
 // node records of rtr_device.h in place.  A different tree finds the same closest hits (every triangle is still reached
 // through boxes that contain it; exact-t ties resolve by triangle handle here, not by the reference's depth-first rank);
@@ -13,12 +13,14 @@
 // node k -> ref node_base + k with its box; a child that is a triangle h -> the bare leaf ref REF_LEAF | REF_TRI |
 // (leaf_base + h), no box (BvhNode::Object has none, bvh.rs:54).
 #include <hip/hip_runtime.h>
-#include <hipcub/hipcub.hpp>
 #include <stdint.h>
 
 #include "rtr_device.h"
 
 namespace rtr {
+
+hipError_t sort_keys_u64(void *temp, size_t &temp_bytes, const unsigned long long *keys_in, unsigned long long *keys_out, uint32_t n,
+                         uint32_t key_bits, hipStream_t stream); // rtr_sort.hip (rocPRIM radix sort)
 
 namespace {
 
@@ -160,9 +162,9 @@ hipError_t lbvh_build(const float *d_boxes, uint32_t n, const float bounds_min[3
     const uint32_t tb = 256u;
     hipLaunchKernelGGL(k_lbvh_keys, dim3((n + tb - 1u) / tb), dim3(tb), 0, stream, d_boxes, n, bmin, inv_ext, keys_in);
     if ((e = hipGetLastError()) != hipSuccess) return done(e);
-    if ((e = hipcub::DeviceRadixSort::SortKeys(nullptr, temp_bytes, keys_in, keys, (int)n, 0, 62, stream)) != hipSuccess) return done(e);
+    if ((e = sort_keys_u64(nullptr, temp_bytes, keys_in, keys, n, 62u, stream)) != hipSuccess) return done(e);
     if ((e = hipMalloc(&temp, temp_bytes ? temp_bytes : 16)) != hipSuccess) return done(e);
-    if ((e = hipcub::DeviceRadixSort::SortKeys(temp, temp_bytes, keys_in, keys, (int)n, 0, 62, stream)) != hipSuccess) return done(e);
+    if ((e = sort_keys_u64(temp, temp_bytes, keys_in, keys, n, 62u, stream)) != hipSuccess) return done(e);
     hipLaunchKernelGGL(k_lbvh_hierarchy, dim3((inner + tb - 1u) / tb), dim3(tb), 0, stream, keys, n, child, parent);
     if ((e = hipGetLastError()) != hipSuccess) return done(e);
     hipLaunchKernelGGL(k_lbvh_emit, dim3((n + tb - 1u) / tb), dim3(tb), 0, stream, keys, d_boxes, n, child, parent, arrived, node_box,
