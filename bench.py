@@ -72,6 +72,10 @@ def parse_args(argv=None):
                     help="scene-level tree over the objects: the reference's median split (parity) or binned SAH")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="headline run only: skip the short secondary measurements of BASELINE's tree configurations")
+    ap.add_argument("--native", action="store_true",
+                    help="N GPUs from ONE process through the C ABI's multi-GPU context (rtr_create_multi: a host thread per "
+                         "GPU, sample split, ncclReduce and resolve inside librtr_hip.so) instead of one torch.distributed "
+                         "rank per GPU; same JSON line")
     ap.add_argument("--tree-kernel", default=None, help="rtr_set_option tree_kernel (auto, stream, samples, resumable, wave)")
     return ap.parse_args(argv)
 
@@ -332,12 +336,19 @@ def main():
     world_env = os.environ.get("WORLD_SIZE")
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
+    if args.native:
+        if int(os.environ.get("RANK", "0")) != 0:
+            return  # started under a launcher: the native path is one process, rank 0's
+        if args.gpus > 1 and visible_gpus() < args.gpus:
+            sys.stderr.write(f"bench.py: --gpus {args.gpus} but only {visible_gpus()} GPU(s) are visible; refusing to run on fewer\n")
+            sys.exit(2)
+        world_env = "1"
     if world_env is None and args.gpus > 1:
         sys.exit(spawn_ranks(args))  # nothing in this process has touched a GPU
     world = int(world_env or "1")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
+    if world != args.gpus and not args.native:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: start one rank per GPU (or let bench.py start them: "
                          f"run it without a launcher)")
     if plumbing_mode():
@@ -373,7 +384,10 @@ def main():
         W, H = args.width, args.height
         scene_name = os.path.basename(args.scene)
 
-    r = rt.Renderer(local_rank)
+    # --native: one context over GPUs 0 .. N-1 (N = 1 included: the same threads, reduce and resolve with one rank)
+    r = rt.Renderer(list(range(args.gpus))) if args.native else rt.Renderer(local_rank)
+    if args.native and args.split == "tiles":
+        r.set_option("multi_split", "tiles")
     r.set_option("mesh_tree", args.mesh_tree)
     r.set_option("scene_tree", args.scene_tree)
     if args.tree_kernel:
@@ -400,6 +414,8 @@ def main():
     def fence():
         if pipe is not None:
             pipe.wait()
+        if args.native:
+            r.stats()  # waits for every GPU of the context (and raises on a device fault)
         torch.cuda.synchronize()
         if distributed:
             dist.barrier()
@@ -444,16 +460,17 @@ def main():
         b_seg = BYTES_PER_SEGMENT.get(args.config, BYTES_PER_SEGMENT["c2"]) if args.config else (
             BYTES_PER_SEGMENT["c2b"] if args.bvh else BYTES_PER_SEGMENT["c2"])
         alg_bytes = b_seg * seg_per_launch + 4.0 * pixels_per_launch
-        prof, prof_status = committed_profile(args, W, H, world)
+        prof, prof_status = committed_profile(args, W, H, args.gpus if args.native else world)
         out = {
-            "metric": "Mrays/s", "value": round(mrays, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps,
+            "metric": "Mrays/s", "value": round(mrays, 2), "unit": "Mrays/s", "n_gpus": args.gpus if args.native else world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {
                 "workload": f"{scene_name} {W}x{H} {args.spp}spp depth {scene.settings.max_ray_depth} "
                             f"clamp {scene.settings.clamp_indirect:g} "
                             f"{'BVH' if scene.settings.enable_bvh_tree else 'linear'} world",
-                "sharding": "single fused kernel" if pipe is None else (
+                "sharding": (f"native: one process, rtr_create_multi over {args.gpus} GPU(s), {args.split} split + ncclReduce + resolve "
+                             f"inside librtr_hip.so") if args.native else "single fused kernel" if pipe is None else (
                     f"samples of every pixel split over {world} ranks + RCCL reduce (sum of partial sums)"
                     if pipe.split == "samples" else f"8x8 tiles round-robin over {world} ranks + RCCL reduce"),
                 "mesh_tree": args.mesh_tree, "scene_tree": args.scene_tree,
@@ -466,7 +483,7 @@ def main():
             },
             "roofline": roofline_block(prof, prof_status, my_integrate_ms, alg_bytes, r.kernel_name()),
         }
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and not (args.native and args.gpus > 1):
             rec, o_rgba, o_spp, o_segments = cpu_baseline(scene, W, H, args.cpu_spp, args.seed)
             out["cpu_baseline"] = rec
             out["config"]["gpu_over_cpu"] = round(mrays / max(rec["value"], 1e-9), 1)

@@ -189,6 +189,24 @@ typedef struct rtr_context rtr_context;
 /* device >= 0: bind that HIP device.  device == -1: host-only context (scene lowering, BVH build and the
  * introspection calls work; every compute call returns RTR_ERR_NO_DEVICE). */
 int rtr_create(int device, rtr_context **out);
+/* One context over the n_devices GPUs device_ids[] of this node (what render()'s rayon fan-out,
+ * lib/core/render.rs:114-119, becomes on a node of GPUs).  rtr_upload_scene replicates the scene on every GPU; rtr_render,
+ * rtr_render_rgba8, rtr_render_f32 and rtr_render_frame_device divide each frame among the GPUs -- by samples (default: every
+ * GPU integrates all pixels for a contiguous share of the samples; the random streams are keyed by the absolute sample
+ * index, so the frame differs from the single-GPU frame only in the order of the float additions across GPUs: ~1e-7
+ * relative, RGBA8 within 1) or by 8x8 tiles (option "multi_split" = "tiles": bit-identical to one GPU) --, sum the GPUs'
+ * partial sums onto device_ids[0] with one ncclReduce per frame (RCCL over xGMI, bound at run time) and resolve there
+ * (mean, sqrt gamma, RGBA8: render.rs:103-110).  One host thread and two streams per GPU; partial sums are double
+ * buffered, so with rtr_render_frame_device -- asynchronous; its d_rgba8 lives on device_ids[0], its stream argument is
+ * ignored -- frame i's reduce and resolve overlap frame i+1's integrate.  rtr_get_stats / rtr_segment_counts add the GPUs'
+ * segments, the *_times_ms calls report the slowest GPU.  The per-shard entry points (rtr_render_tiles_device,
+ * rtr_render_samples_device) return RTR_ERR_UNSUPPORTED on such a context.
+ * device_ids must be distinct; all -1: a host-only context; all the same GPU: a test configuration without RCCL (the
+ * partial sums are added by a kernel).  n_devices = 1 is a single-GPU context that goes through the same reduce. */
+int rtr_create_multi(const int *device_ids, int n_devices, rtr_context **out);
+/* The samples [*begin, *begin + *count) of a frame of samples_per_pixel samples that GPU `rank` of `n_ranks` integrates
+ * under the sample split: contiguous, the first samples_per_pixel % n_ranks ranks take one more.  Pure arithmetic. */
+int rtr_sample_range(uint32_t rank, uint32_t n_ranks, uint32_t samples_per_pixel, uint32_t *begin, uint32_t *count);
 void rtr_destroy(rtr_context *ctx);
 /* message for the last failing call on ctx (ctx == NULL: last failing rtr_create on this thread) */
 const char *rtr_last_error(const rtr_context *ctx);
@@ -228,6 +246,7 @@ int rtr_abi_version(void);
  *                 them: bit-identical frames.  "auto": trees of 32 leaves or more
  *                 take "samples" (inside tile-sharded launches, where it does not apply: "resumable" for scenes with
  *                 meshes, else "wave"); smaller trees "wave". */
+/*   "multi_split" = "samples" (default) | "tiles" (contexts of rtr_create_multi; applied at the next render): see there. */
 /*   "samples_batch" = "0" (default: what half of the free device memory holds, at most 16 GiB of radiance and 64
  *                 samples for "stream") | N: samples per batch of the "samples" / "stream" kernels' buffers; a pixel's
  *                 running sum is carried from batch to batch, so any N gives the same frame.  A batch whose allocation

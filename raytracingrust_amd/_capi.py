@@ -88,6 +88,8 @@ _ctx = C.c_void_p
 SYMBOLS = [
     ("rtr_abi_version", C.c_int, []),
     ("rtr_create", C.c_int, [C.c_int, C.POINTER(_ctx)]),
+    ("rtr_create_multi", C.c_int, [C.POINTER(C.c_int), C.c_int, C.POINTER(_ctx)]),
+    ("rtr_sample_range", C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     ("rtr_destroy", None, [_ctx]),
     ("rtr_last_error", C.c_char_p, [_ctx]),
     ("rtr_set_option", C.c_int, [_ctx, C.c_char_p, C.c_char_p]),

@@ -4,8 +4,15 @@
 // render kernels and a ring of device-side segment counters.  There is no CPU rendering path in this
 // library: without a device every compute entry point returns RTR_ERR_NO_DEVICE.
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h> // types and prototypes only: RCCL is bound at run time (load_rccl)
+
+#include <dlfcn.h>
 
 #include <chrono>
+#include <condition_variable>
+#include <functional>
+#include <memory>
+#include <thread>
 #include <cstdio>
 #include <algorithm>
 #include <cstdlib>
@@ -40,6 +47,7 @@ uint32_t wf_intersect_lds_bytes(const RenderParams &p);
 uint32_t stack_entry_bytes(const RenderParams &p);
 hipError_t wf_intersect_attributes(const RenderParams &p, int *vgprs);
 hipError_t launch_selftest_div(float d, uint32_t lo_bits, uint32_t hi_bits, unsigned long long *d_mismatches, hipStream_t stream);
+hipError_t launch_sum_partials(const float *const *d_partials, uint32_t n, uint32_t n_pixels, float *d_total, hipStream_t stream);
 hipError_t launch_probe_hits(const RenderParams &p, const float *d_origins, const float *d_dirs, uint32_t n, uint32_t *d_out, hipStream_t stream);
 } // namespace rtr
 
@@ -53,9 +61,14 @@ hipError_t launch_probe_hits(const RenderParams &p, const float *d_origins, cons
 namespace {
 constexpr int kRing = 64;
 thread_local std::string g_create_error;
+struct MultiState;
 } // namespace
 
 struct rtr_context {
+    // rtr_create_multi: the contexts of the GPUs this one spans (empty: an ordinary single-device context) and the
+    // communication state; `device` is then the first GPU's, where frames are resolved
+    std::vector<rtr_context *> ranks;
+    MultiState *multi = nullptr;
     int device = -1; // -1: host-only
     hipStream_t stream = nullptr;
     std::string error;
@@ -479,90 +492,10 @@ int launch_frame(rtr_context *ctx, const rtr_camera *camera, const rtr_settings 
 }
 
 
-} // namespace
-
-extern "C" {
-
-int rtr_abi_version(void) { return RTR_ABI_VERSION; }
-
-int rtr_create(int device, rtr_context **out) {
-    if (!out) { g_create_error = "null out pointer"; return RTR_ERR_INVALID_ARGUMENT; }
-    *out = nullptr;
-    rtr_context *ctx = new (std::nothrow) rtr_context();
-    if (!ctx) { g_create_error = "out of memory"; return RTR_ERR_OUT_OF_MEMORY; }
-    if (device < 0) { // host-only
-        ctx->device = -1;
-        *out = ctx;
-        return RTR_OK;
-    }
-    int count = 0;
-    hipError_t e = hipGetDeviceCount(&count);
-    if (e != hipSuccess || count <= 0 || device >= count) {
-        g_create_error = std::string("no usable HIP device ") + std::to_string(device) + " (" +
-                         (e != hipSuccess ? hipGetErrorString(e) : "device count too small") + "); there is no CPU fallback";
-        delete ctx;
-        return RTR_ERR_NO_DEVICE;
-    }
-    auto bail = [&](hipError_t err, const char *what) {
-        g_create_error = std::string(what) + ": " + hipGetErrorString(err);
-        rtr_destroy(ctx);
-        return (int)RTR_ERR_HIP;
-    };
-    ctx->device = device;
-    if ((e = hipSetDevice(device)) != hipSuccess) { ctx->device = -1; return bail(e, "hipSetDevice"); }
-    if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
-    for (int i = 0; i < kRing; i++) {
-        if ((e = hipEventCreate(&ctx->ev_start[i])) != hipSuccess) return bail(e, "hipEventCreate");
-        if ((e = hipEventCreate(&ctx->ev_stop[i])) != hipSuccess) return bail(e, "hipEventCreate");
-        if ((e = hipEventCreate(&ctx->ev_mid[i])) != hipSuccess) return bail(e, "hipEventCreate");
-    }
-    if ((e = hipEventCreate(&ctx->ev_res_start)) != hipSuccess) return bail(e, "hipEventCreate");
-    if ((e = hipEventCreate(&ctx->ev_res_stop)) != hipSuccess) return bail(e, "hipEventCreate");
-    // kRing segment counters and the sticky fault word
-    if ((e = hipMalloc((void **)&ctx->d_counters, (kRing + 1) * sizeof(unsigned long long))) != hipSuccess) return bail(e, "hipMalloc");
-    if ((e = hipMemset(ctx->d_counters, 0, (kRing + 1) * sizeof(unsigned long long))) != hipSuccess) return bail(e, "hipMemset");
-    if ((e = hipMalloc((void **)&ctx->d_work, 256)) != hipSuccess) return bail(e, "hipMalloc");
-    *out = ctx;
-    return RTR_OK;
-}
-
-void rtr_destroy(rtr_context *ctx) {
-    if (!ctx) return;
-    if (ctx->device >= 0) {
-        (void)hipSetDevice(ctx->device);
-        if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-        free_scene(ctx);
-        for (int i = 0; i < kRing; i++) {
-            if (ctx->ev_start[i]) (void)hipEventDestroy(ctx->ev_start[i]);
-            if (ctx->ev_stop[i]) (void)hipEventDestroy(ctx->ev_stop[i]);
-            if (ctx->ev_mid[i]) (void)hipEventDestroy(ctx->ev_mid[i]);
-        }
-        if (ctx->ev_res_start) (void)hipEventDestroy(ctx->ev_res_start);
-        if (ctx->ev_res_stop) (void)hipEventDestroy(ctx->ev_res_stop);
-        if (ctx->d_counters) (void)hipFree(ctx->d_counters);
-        if (ctx->d_carry) (void)hipFree(ctx->d_carry);
-        if (ctx->d_samples) (void)hipFree(ctx->d_samples);
-        if (ctx->d_wf) (void)hipFree(ctx->d_wf);
-        if (ctx->d_work) (void)hipFree(ctx->d_work);
-        if (ctx->d_chunk_flags) (void)hipFree(ctx->d_chunk_flags);
-        if (ctx->d_rgba8) (void)hipFree(ctx->d_rgba8);
-        if (ctx->d_mean) (void)hipFree(ctx->d_mean);
-        if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
-    }
-    delete ctx;
-}
-
-const char *rtr_last_error(const rtr_context *ctx) { return ctx ? ctx->error.c_str() : g_create_error.c_str(); }
-
-int rtr_upload_scene(rtr_context *ctx, const rtr_scene_desc *scene) {
-    if (!ctx) return RTR_ERR_INVALID_ARGUMENT;
-    RTR_LOCK(ctx);
-    if (!scene) return fail(ctx, RTR_ERR_INVALID_ARGUMENT, "null scene");
-    auto t0 = std::chrono::steady_clock::now();
-    rtr::FlatScene flat;
-    std::string err;
-    int rc = rtr::build_flat_scene(*scene, flat, err, ctx->build_options);
-    if (rc != RTR_OK) return fail(ctx, rc, err);
+// The device half of rtr_upload_scene: copy a flattened scene to the context's GPU (and run the device-side tree builder
+// where the scene asks for one); `flat` is consumed.
+int install_scene(rtr_context *ctx, rtr::FlatScene &flat, std::chrono::steady_clock::time_point t0) {
+    int rc = RTR_OK;
     if (ctx->device < 0 && !flat.lbvh_jobs.empty())
         return fail(ctx, RTR_ERR_NO_DEVICE, "mesh_tree = \"lbvh\" builds the mesh trees on the device: not available in a host-only context");
     if (ctx->device >= 0) {
@@ -610,6 +543,443 @@ int rtr_upload_scene(rtr_context *ctx, const rtr_scene_desc *scene) {
     ctx->have_scene = true;
     ctx->upload_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return RTR_OK;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// One context over several GPUs (rtr_create_multi): render() -- lib/core/render.rs:61,114-119,
+// the reference's rayon fan-out over pixels -- becomes a fan-out over devices.  The scene is replicated; a frame is split
+// by SAMPLES (every rank integrates all pixels for a contiguous share of the samples: the random streams are keyed by the
+// absolute sample index, so the ranks draw exactly the single-GPU numbers and every GPU keeps a full grid of waves) or by
+// TILES (option "multi_split"); the ranks' float4 partial sums are summed onto rank 0 with ONE ncclReduce over xGMI per
+// frame and rank 0 runs k_resolve (sum / spp, sqrt gamma, RGBA8: render.rs:103-110 must follow the reduce).  One host
+// thread per GPU issues that GPU's work (its own compute and communication streams); partial-sum buffers are double
+// buffered, so frame i's reduce + resolve overlap frame i+1's integrate.
+// RCCL is bound at run time (dlopen of librccl.so.1: the copy the process already holds -- PyTorch's -- or ROCm's), so the
+// library carries no link-time dependency on it and single-GPU contexts never load it.
+struct RcclApi {
+    void *handle = nullptr;
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclReduce) Reduce = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+};
+bool load_rccl(RcclApi &api, std::string &err) {
+    static std::mutex mu;
+    static RcclApi cached;
+    std::lock_guard<std::mutex> g(mu);
+    if (!cached.handle) {
+        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            cached.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (cached.handle) break;
+        }
+        if (!cached.handle) { err = std::string("cannot load RCCL (librccl.so.1): ") + dlerror(); return false; }
+        cached.CommInitAll = reinterpret_cast<decltype(&ncclCommInitAll)>(dlsym(cached.handle, "ncclCommInitAll"));
+        cached.CommDestroy = reinterpret_cast<decltype(&ncclCommDestroy)>(dlsym(cached.handle, "ncclCommDestroy"));
+        cached.Reduce = reinterpret_cast<decltype(&ncclReduce)>(dlsym(cached.handle, "ncclReduce"));
+        cached.GetErrorString = reinterpret_cast<decltype(&ncclGetErrorString)>(dlsym(cached.handle, "ncclGetErrorString"));
+        if (!cached.CommInitAll || !cached.CommDestroy || !cached.Reduce || !cached.GetErrorString) {
+            err = "librccl.so.1 lacks ncclCommInitAll / ncclReduce";
+            cached = RcclApi();
+            return false;
+        }
+    }
+    api = cached;
+    return true;
+}
+
+// One host thread per GPU: runs the jobs it is handed, in order.
+class RankWorker {
+  public:
+    RankWorker() : th_([this] { loop(); }) {}
+    ~RankWorker() {
+        { std::lock_guard<std::mutex> g(mu_); stop_ = true; }
+        cv_.notify_all();
+        th_.join();
+    }
+    void post(std::function<void()> job) {
+        { std::lock_guard<std::mutex> g(mu_); job_ = std::move(job); busy_ = true; }
+        cv_.notify_all();
+    }
+    void wait() {
+        std::unique_lock<std::mutex> g(mu_);
+        cv_.wait(g, [this] { return !busy_; });
+    }
+
+  private:
+    void loop() {
+        std::unique_lock<std::mutex> g(mu_);
+        for (;;) {
+            cv_.wait(g, [this] { return stop_ || busy_; });
+            if (stop_) return;
+            std::function<void()> job = std::move(job_);
+            g.unlock();
+            job();
+            g.lock();
+            busy_ = false;
+            cv_.notify_all();
+        }
+    }
+    std::mutex mu_;
+    std::condition_variable cv_;
+    std::function<void()> job_;
+    bool busy_ = false, stop_ = false;
+    std::thread th_;
+};
+
+struct MultiState {
+    bool same_device = false;      // every rank on one GPU (test configuration): the partial sums are added by a kernel, no RCCL
+    bool split_tiles = false;      // option "multi_split" = "tiles"
+    RcclApi rccl;
+    std::vector<ncclComm_t> comms; // one per rank (distinct devices only)
+    std::vector<std::unique_ptr<RankWorker>> workers;
+    std::vector<hipStream_t> comm_stream;              // per rank, beside the rank context's compute stream
+    std::vector<hipEvent_t> ev_integrated[2], ev_reduced[2]; // per buffer, per rank
+    std::vector<void *> d_sum[2];  // per buffer, per rank: float4 partial sums of a frame
+    void *d_total[2] = {nullptr, nullptr}; // rank 0: the reduced sums
+    size_t sum_cap = 0;
+    void *d_ptrs = nullptr;        // same_device: the ranks' buffer addresses for the adding kernel
+    uint64_t frames = 0;
+    std::vector<int> rank_rc;      // status of each rank's last job
+};
+
+// rank r's samples of a frame: contiguous, the first spp % n ranks take one more (raytracingrust_amd/distributed.py sample_range)
+void multi_sample_range(uint32_t rank, uint32_t n, uint32_t spp, uint32_t &begin, uint32_t &count) {
+    const uint32_t base = spp / n, extra = spp % n;
+    begin = rank * base + std::min(rank, extra);
+    count = base + (rank < extra ? 1u : 0u);
+}
+
+int multi_fail(rtr_context *ctx, const rtr_context *rank, int rc, uint32_t r) {
+    return fail(ctx, rc, "GPU " + std::to_string(rank->device) + " (rank " + std::to_string(r) + "): " + rank->error);
+}
+
+int multi_upload(rtr_context *ctx, rtr::FlatScene &flat, std::chrono::steady_clock::time_point t0) {
+    const size_t n = ctx->ranks.size();
+    std::vector<rtr::FlatScene> copies(n);
+    for (size_t r = 0; r + 1 < n; r++) copies[r] = flat;
+    copies[n - 1] = std::move(flat);
+    MultiState &m = *ctx->multi;
+    for (size_t r = 0; r < n; r++) {
+        rtr_context *rk = ctx->ranks[r];
+        rk->sky_bilinear = ctx->sky_bilinear;
+        m.workers[r]->post([&m, rk, &copies, r, t0] { std::lock_guard<std::recursive_mutex> g(rk->mu); m.rank_rc[r] = install_scene(rk, copies[r], t0); });
+    }
+    for (size_t r = 0; r < n; r++) m.workers[r]->wait();
+    for (size_t r = 0; r < n; r++)
+        if (m.rank_rc[r]) return multi_fail(ctx, ctx->ranks[r], m.rank_rc[r], (uint32_t)r);
+    ctx->have_scene = true;
+    ctx->upload_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return RTR_OK;
+}
+
+void multi_free_buffers(rtr_context *ctx) {
+    MultiState &m = *ctx->multi;
+    for (size_t r = 0; r < ctx->ranks.size(); r++) {
+        if (ctx->ranks[r]->device < 0) continue;
+        (void)hipSetDevice(ctx->ranks[r]->device);
+        for (int b = 0; b < 2; b++) {
+            if (r < m.d_sum[b].size() && m.d_sum[b][r]) (void)hipFree(m.d_sum[b][r]);
+            if (r < m.d_sum[b].size()) m.d_sum[b][r] = nullptr;
+        }
+    }
+    if (ctx->ranks[0]->device >= 0) {
+        (void)hipSetDevice(ctx->ranks[0]->device);
+        for (int b = 0; b < 2; b++) { if (m.d_total[b]) (void)hipFree(m.d_total[b]); m.d_total[b] = nullptr; }
+    }
+    m.sum_cap = 0;
+}
+
+// One frame over every GPU of the context, asynchronous: returns when every rank's work has been issued.  d_rgba8 /
+// d_mean_rgb live on the first GPU.  The caller holds ctx->mu.
+int multi_frame(rtr_context *ctx, const rtr_camera *camera, const rtr_settings *st, uint32_t width, uint32_t height, uint64_t seed,
+                uint8_t *d_rgba8, float *d_mean_rgb) {
+    MultiState &m = *ctx->multi;
+    const uint32_t n = (uint32_t)ctx->ranks.size();
+    if (ctx->ranks[0]->device < 0) return fail(ctx, RTR_ERR_NO_DEVICE, "host-only context: no HIP device bound (there is no CPU fallback)");
+    if (!ctx->have_scene) return fail(ctx, RTR_ERR_NO_SCENE, "rtr_upload_scene has not been called");
+    int rc = check_settings(ctx, camera, st, width, height);
+    if (rc) return rc;
+    const size_t bytes = (size_t)width * height * 4u * sizeof(float);
+    if (m.sum_cap < bytes) { // (re)allocate the partial-sum buffers: waits for the frames in flight
+        for (uint32_t r = 0; r < n; r++) { (void)hipSetDevice(ctx->ranks[r]->device); (void)hipDeviceSynchronize(); }
+        multi_free_buffers(ctx);
+        for (uint32_t r = 0; r < n; r++) {
+            RTR_HIP_TRY(ctx, hipSetDevice(ctx->ranks[r]->device));
+            for (int b = 0; b < 2; b++) RTR_HIP_TRY(ctx, hipMalloc(&m.d_sum[b][r], bytes));
+        }
+        RTR_HIP_TRY(ctx, hipSetDevice(ctx->ranks[0]->device));
+        for (int b = 0; b < 2; b++) RTR_HIP_TRY(ctx, hipMalloc(&m.d_total[b], bytes));
+        m.sum_cap = bytes;
+        m.frames = 0;
+    }
+    const int buf = (int)(m.frames & 1u);
+    const bool reuse = m.frames >= 2u; // the buffer's previous frame must have been reduced before it is overwritten
+    const bool tiles = m.split_tiles;
+    const rtr_camera cam = *camera;
+    const rtr_settings settings = *st;
+    if (m.same_device) { // test configuration: the ranks' buffer addresses for the adding kernel
+        std::vector<const float *> ptrs(n);
+        for (uint32_t r = 0; r < n; r++) ptrs[r] = static_cast<const float *>(m.d_sum[buf][r]);
+        RTR_HIP_TRY(ctx, hipSetDevice(ctx->ranks[0]->device));
+        if (!m.d_ptrs) RTR_HIP_TRY(ctx, hipMalloc(&m.d_ptrs, 64u * sizeof(void *)));
+        RTR_HIP_TRY(ctx, hipMemcpyAsync(m.d_ptrs, ptrs.data(), n * sizeof(void *), hipMemcpyHostToDevice, m.comm_stream[0]));
+        RTR_HIP_TRY(ctx, hipStreamSynchronize(m.comm_stream[0])); // (ptrs is a local)
+    }
+    for (uint32_t r = 0; r < n; r++) {
+        rtr_context *rk = ctx->ranks[r];
+        rk->tree_kernel = ctx->tree_kernel; rk->sample_chunks = ctx->sample_chunks; rk->block_samples = ctx->block_samples;
+        rk->samples_batch = ctx->samples_batch; rk->stack_wide = ctx->stack_wide; rk->sky_bilinear = ctx->sky_bilinear;
+        rk->chunk_timeout_s = ctx->chunk_timeout_s; rk->wf_flush = ctx->wf_flush; rk->debug_fault = ctx->debug_fault;
+        m.workers[r]->post([&m, ctx, rk, r, n, buf, reuse, tiles, cam, settings, width, height, seed, bytes, d_rgba8, d_mean_rgb] {
+            std::lock_guard<std::recursive_mutex> g(rk->mu);
+            int &out = m.rank_rc[r];
+            out = RTR_OK;
+            auto hip = [&](hipError_t e, const char *what) { if (e != hipSuccess && out == RTR_OK) out = fail_hip(rk, e, what); return e == hipSuccess; };
+            if (!hip(hipSetDevice(rk->device), "hipSetDevice")) return;
+            float *sum = static_cast<float *>(m.d_sum[buf][r]);
+            if (reuse && !hip(hipStreamWaitEvent(rk->stream, m.ev_reduced[buf][r], 0), "hipStreamWaitEvent")) return;
+            if (tiles) {
+                if (!hip(hipMemsetAsync(sum, 0, bytes, rk->stream), "hipMemsetAsync")) return;
+                out = launch_frame(rk, &cam, &settings, width, height, seed, r, n, sum, nullptr, nullptr, rk->stream);
+            } else {
+                uint32_t begin, count;
+                multi_sample_range(r, n, settings.samples_per_pixel, begin, count);
+                out = launch_frame(rk, &cam, &settings, width, height, seed, 0u, 1u, sum, nullptr, nullptr, rk->stream, begin, count);
+            }
+            if (out) return;
+            if (!hip(hipEventRecord(m.ev_integrated[buf][r], rk->stream), "hipEventRecord")) return;
+            hipStream_t cs = m.comm_stream[r];
+            if (!m.same_device) {
+                if (!hip(hipStreamWaitEvent(cs, m.ev_integrated[buf][r], 0), "hipStreamWaitEvent")) return;
+                const ncclResult_t nr = m.rccl.Reduce(sum, r == 0 ? m.d_total[buf] : nullptr, (size_t)width * height * 4u, ncclFloat, ncclSum, 0,
+                                                      m.comms[r], cs);
+                if (nr != ncclSuccess) { out = fail(rk, RTR_ERR_HIP, std::string("ncclReduce: ") + m.rccl.GetErrorString(nr)); return; }
+                if (!hip(hipEventRecord(m.ev_reduced[buf][r], cs), "hipEventRecord")) return;
+            }
+            (void)ctx; (void)d_rgba8; (void)d_mean_rgb;
+        });
+    }
+    for (uint32_t r = 0; r < n; r++) m.workers[r]->wait();
+    for (uint32_t r = 0; r < n; r++)
+        if (m.rank_rc[r]) return multi_fail(ctx, ctx->ranks[r], m.rank_rc[r], r);
+    // rank 0, communication stream: (same device: add the partial sums in rank order) then resolve
+    rtr_context *root = ctx->ranks[0];
+    RTR_HIP_TRY(ctx, hipSetDevice(root->device));
+    hipStream_t cs = m.comm_stream[0];
+    if (m.same_device) {
+        for (uint32_t r = 0; r < n; r++) RTR_HIP_TRY(ctx, hipStreamWaitEvent(cs, m.ev_integrated[buf][r], 0));
+        RTR_HIP_TRY(ctx, rtr::launch_sum_partials(static_cast<const float *const *>(m.d_ptrs), n, width * height, static_cast<float *>(m.d_total[buf]), cs));
+        for (uint32_t r = 0; r < n; r++) RTR_HIP_TRY(ctx, hipEventRecord(m.ev_reduced[buf][r], cs));
+    }
+    RTR_HIP_TRY(ctx, rtr::launch_resolve(static_cast<const float *>(m.d_total[buf]), st->samples_per_pixel, width * height, d_rgba8, d_mean_rgb, cs));
+    RTR_HIP_TRY(ctx, hipEventRecord(ctx->ev_res_stop, cs)); // (the multi context's own event: the frame is complete)
+    m.frames++;
+    ctx->launches++;
+    return RTR_OK;
+}
+
+// waits for every GPU of the context and reports a rank's device fault
+int multi_sync(rtr_context *ctx) {
+    for (size_t r = 0; r < ctx->ranks.size(); r++) {
+        rtr_context *rk = ctx->ranks[r];
+        if (rk->device < 0) continue;
+        RTR_HIP_TRY(ctx, hipSetDevice(rk->device));
+        RTR_HIP_TRY(ctx, hipDeviceSynchronize());
+    }
+    int first = RTR_OK; // every rank's fault word is read (and cleared): one bad frame fails one call
+    for (size_t r = 0; r < ctx->ranks.size(); r++) {
+        rtr_context *rk = ctx->ranks[r];
+        if (rk->device < 0 || rk->launches == 0) continue;
+        const int rc = check_fault(rk);
+        if (rc && !first) first = multi_fail(ctx, rk, rc, (uint32_t)r);
+    }
+    return first;
+}
+
+} // namespace
+
+extern "C" {
+
+int rtr_abi_version(void) { return RTR_ABI_VERSION; }
+
+int rtr_create(int device, rtr_context **out) {
+    if (!out) { g_create_error = "null out pointer"; return RTR_ERR_INVALID_ARGUMENT; }
+    *out = nullptr;
+    rtr_context *ctx = new (std::nothrow) rtr_context();
+    if (!ctx) { g_create_error = "out of memory"; return RTR_ERR_OUT_OF_MEMORY; }
+    if (device < 0) { // host-only
+        ctx->device = -1;
+        *out = ctx;
+        return RTR_OK;
+    }
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0 || device >= count) {
+        g_create_error = std::string("no usable HIP device ") + std::to_string(device) + " (" +
+                         (e != hipSuccess ? hipGetErrorString(e) : "device count too small") + "); there is no CPU fallback";
+        delete ctx;
+        return RTR_ERR_NO_DEVICE;
+    }
+    auto bail = [&](hipError_t err, const char *what) {
+        g_create_error = std::string(what) + ": " + hipGetErrorString(err);
+        rtr_destroy(ctx);
+        return (int)RTR_ERR_HIP;
+    };
+    ctx->device = device;
+    if ((e = hipSetDevice(device)) != hipSuccess) { ctx->device = -1; return bail(e, "hipSetDevice"); }
+    if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
+    for (int i = 0; i < kRing; i++) {
+        if ((e = hipEventCreate(&ctx->ev_start[i])) != hipSuccess) return bail(e, "hipEventCreate");
+        if ((e = hipEventCreate(&ctx->ev_stop[i])) != hipSuccess) return bail(e, "hipEventCreate");
+        if ((e = hipEventCreate(&ctx->ev_mid[i])) != hipSuccess) return bail(e, "hipEventCreate");
+    }
+    if ((e = hipEventCreate(&ctx->ev_res_start)) != hipSuccess) return bail(e, "hipEventCreate");
+    if ((e = hipEventCreate(&ctx->ev_res_stop)) != hipSuccess) return bail(e, "hipEventCreate");
+    // kRing segment counters and the sticky fault word
+    if ((e = hipMalloc((void **)&ctx->d_counters, (kRing + 1) * sizeof(unsigned long long))) != hipSuccess) return bail(e, "hipMalloc");
+    if ((e = hipMemset(ctx->d_counters, 0, (kRing + 1) * sizeof(unsigned long long))) != hipSuccess) return bail(e, "hipMemset");
+    if ((e = hipMalloc((void **)&ctx->d_work, 256)) != hipSuccess) return bail(e, "hipMalloc");
+    *out = ctx;
+    return RTR_OK;
+}
+
+int rtr_sample_range(uint32_t rank, uint32_t n_ranks, uint32_t samples_per_pixel, uint32_t *begin, uint32_t *count) {
+    if (!begin || !count || n_ranks == 0u || rank >= n_ranks) return RTR_ERR_INVALID_ARGUMENT;
+    multi_sample_range(rank, n_ranks, samples_per_pixel, *begin, *count);
+    return RTR_OK;
+}
+
+int rtr_create_multi(const int *device_ids, int n_devices, rtr_context **out) {
+    if (!out) { g_create_error = "null out pointer"; return RTR_ERR_INVALID_ARGUMENT; }
+    *out = nullptr;
+    if (!device_ids || n_devices < 1 || n_devices > 64) { g_create_error = "rtr_create_multi: 1 to 64 devices"; return RTR_ERR_INVALID_ARGUMENT; }
+    const uint32_t n = (uint32_t)n_devices;
+    bool all_same = true, all_distinct = true, any_host = false, all_host = true;
+    for (uint32_t i = 0; i < n; i++) {
+        any_host |= device_ids[i] < 0; all_host &= device_ids[i] < 0;
+        for (uint32_t j = 0; j < i; j++) { if (device_ids[i] == device_ids[j]) all_distinct = false; else all_same = false; }
+    }
+    if (any_host && !all_host) { g_create_error = "rtr_create_multi: host-only (-1) and GPU ranks cannot be mixed"; return RTR_ERR_INVALID_ARGUMENT; }
+    if (!all_host && !all_distinct && !all_same) {
+        g_create_error = "rtr_create_multi: device ids must be all distinct (or all the same device: a test configuration)";
+        return RTR_ERR_INVALID_ARGUMENT;
+    }
+    rtr_context *ctx = new (std::nothrow) rtr_context();
+    if (!ctx) { g_create_error = "out of memory"; return RTR_ERR_OUT_OF_MEMORY; }
+    ctx->multi = new (std::nothrow) MultiState();
+    if (!ctx->multi) { delete ctx; g_create_error = "out of memory"; return RTR_ERR_OUT_OF_MEMORY; }
+    MultiState &m = *ctx->multi;
+    auto bail = [&](int code, const std::string &msg) {
+        g_create_error = msg;
+        rtr_destroy(ctx);
+        return code;
+    };
+    for (uint32_t r = 0; r < n; r++) {
+        rtr_context *rk = nullptr;
+        const int rc = rtr_create(device_ids[r], &rk);
+        if (rc != RTR_OK) return bail(rc, g_create_error);
+        ctx->ranks.push_back(rk);
+    }
+    ctx->device = ctx->ranks[0]->device;
+    m.same_device = !all_host && n > 1u && all_same;
+    m.rank_rc.assign(n, RTR_OK);
+    for (int b = 0; b < 2; b++) { m.d_sum[b].assign(n, nullptr); m.ev_integrated[b].assign(n, nullptr); m.ev_reduced[b].assign(n, nullptr); }
+    m.comm_stream.assign(n, nullptr);
+    for (uint32_t r = 0; r < n; r++) m.workers.emplace_back(new RankWorker());
+    if (all_host) { *out = ctx; return RTR_OK; } // host-only: scene lowering and introspection; every compute call fails
+    for (uint32_t r = 0; r < n; r++) {
+        hipError_t e = hipSetDevice(device_ids[r]);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&m.comm_stream[r], hipStreamNonBlocking);
+        for (int b = 0; b < 2 && e == hipSuccess; b++) {
+            e = hipEventCreateWithFlags(&m.ev_integrated[b][r], hipEventDisableTiming);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&m.ev_reduced[b][r], hipEventDisableTiming);
+        }
+        if (e != hipSuccess) return bail(RTR_ERR_HIP, std::string("rtr_create_multi: ") + hipGetErrorString(e));
+    }
+    {
+        hipError_t e = hipSetDevice(ctx->device);
+        if (e == hipSuccess) e = hipEventCreate(&ctx->ev_res_stop);
+        if (e != hipSuccess) return bail(RTR_ERR_HIP, std::string("rtr_create_multi: ") + hipGetErrorString(e));
+    }
+    if (!m.same_device) { // one communicator per GPU, all created by this process (ncclCommInitAll)
+        std::string err;
+        if (!load_rccl(m.rccl, err)) return bail(RTR_ERR_UNSUPPORTED, err);
+        m.comms.assign(n, nullptr);
+        const ncclResult_t nr = m.rccl.CommInitAll(m.comms.data(), (int)n, device_ids);
+        if (nr != ncclSuccess) { m.comms.clear(); return bail(RTR_ERR_HIP, std::string("ncclCommInitAll: ") + m.rccl.GetErrorString(nr)); }
+    }
+    *out = ctx;
+    return RTR_OK;
+}
+
+void rtr_destroy(rtr_context *ctx) {
+    if (!ctx) return;
+    if (ctx->multi) {
+        MultiState &m = *ctx->multi;
+        for (rtr_context *rk : ctx->ranks)
+            if (rk->device >= 0) { (void)hipSetDevice(rk->device); (void)hipDeviceSynchronize(); }
+        m.workers.clear(); // joins the rank threads
+        for (ncclComm_t c : m.comms) if (c) (void)m.rccl.CommDestroy(c);
+        if (!ctx->ranks.empty()) multi_free_buffers(ctx);
+        for (size_t r = 0; r < ctx->ranks.size(); r++) {
+            if (ctx->ranks[r]->device < 0) continue;
+            (void)hipSetDevice(ctx->ranks[r]->device);
+            if (r < m.comm_stream.size() && m.comm_stream[r]) (void)hipStreamDestroy(m.comm_stream[r]);
+            for (int b = 0; b < 2; b++) {
+                if (r < m.ev_integrated[b].size() && m.ev_integrated[b][r]) (void)hipEventDestroy(m.ev_integrated[b][r]);
+                if (r < m.ev_reduced[b].size() && m.ev_reduced[b][r]) (void)hipEventDestroy(m.ev_reduced[b][r]);
+            }
+        }
+        if (ctx->device >= 0) {
+            (void)hipSetDevice(ctx->device);
+            if (m.d_ptrs) (void)hipFree(m.d_ptrs);
+            if (ctx->ev_res_stop) (void)hipEventDestroy(ctx->ev_res_stop);
+            if (ctx->d_rgba8) (void)hipFree(ctx->d_rgba8);
+            if (ctx->d_mean) (void)hipFree(ctx->d_mean);
+        }
+        for (rtr_context *rk : ctx->ranks) rtr_destroy(rk);
+        delete ctx->multi;
+        delete ctx;
+        return;
+    }
+    if (ctx->device >= 0) {
+        (void)hipSetDevice(ctx->device);
+        if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+        free_scene(ctx);
+        for (int i = 0; i < kRing; i++) {
+            if (ctx->ev_start[i]) (void)hipEventDestroy(ctx->ev_start[i]);
+            if (ctx->ev_stop[i]) (void)hipEventDestroy(ctx->ev_stop[i]);
+            if (ctx->ev_mid[i]) (void)hipEventDestroy(ctx->ev_mid[i]);
+        }
+        if (ctx->ev_res_start) (void)hipEventDestroy(ctx->ev_res_start);
+        if (ctx->ev_res_stop) (void)hipEventDestroy(ctx->ev_res_stop);
+        if (ctx->d_counters) (void)hipFree(ctx->d_counters);
+        if (ctx->d_carry) (void)hipFree(ctx->d_carry);
+        if (ctx->d_samples) (void)hipFree(ctx->d_samples);
+        if (ctx->d_wf) (void)hipFree(ctx->d_wf);
+        if (ctx->d_work) (void)hipFree(ctx->d_work);
+        if (ctx->d_chunk_flags) (void)hipFree(ctx->d_chunk_flags);
+        if (ctx->d_rgba8) (void)hipFree(ctx->d_rgba8);
+        if (ctx->d_mean) (void)hipFree(ctx->d_mean);
+        if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    }
+    delete ctx;
+}
+
+const char *rtr_last_error(const rtr_context *ctx) { return ctx ? ctx->error.c_str() : g_create_error.c_str(); }
+
+int rtr_upload_scene(rtr_context *ctx, const rtr_scene_desc *scene) {
+    if (!ctx) return RTR_ERR_INVALID_ARGUMENT;
+    RTR_LOCK(ctx);
+    if (!scene) return fail(ctx, RTR_ERR_INVALID_ARGUMENT, "null scene");
+    auto t0 = std::chrono::steady_clock::now();
+    rtr::FlatScene flat;
+    std::string err;
+    int rc = rtr::build_flat_scene(*scene, flat, err, ctx->build_options);
+    if (rc != RTR_OK) return fail(ctx, rc, err);
+    if (!ctx->ranks.empty()) return multi_upload(ctx, flat, t0); // replicated on every GPU of the context
+    return install_scene(ctx, flat, t0);
 }
 
 int rtr_set_option(rtr_context *ctx, const char *name, const char *value) {
@@ -707,6 +1077,13 @@ int rtr_set_option(rtr_context *ctx, const char *name, const char *value) {
         else return fail(ctx, RTR_ERR_INVALID_ARGUMENT, "debug_fault must be \"on\" or \"off\"");
         return RTR_OK;
     }
+    if (n == "multi_split") { // rtr_create_multi contexts: how a frame is divided among the GPUs (applied at the next render)
+        if (!ctx->multi) return fail(ctx, RTR_ERR_INVALID_ARGUMENT, "multi_split applies to contexts made by rtr_create_multi");
+        if (v == "samples") ctx->multi->split_tiles = false;
+        else if (v == "tiles") ctx->multi->split_tiles = true;
+        else return fail(ctx, RTR_ERR_INVALID_ARGUMENT, "multi_split must be \"samples\" or \"tiles\"");
+        return RTR_OK;
+    }
     if (n == "leaf_pairs") {
         if (v == "on") ctx->build_options.leaf_pairs = true;
         else if (v == "off") ctx->build_options.leaf_pairs = false;
@@ -718,6 +1095,7 @@ int rtr_set_option(rtr_context *ctx, const char *name, const char *value) {
 
 int rtr_scene_info_get(const rtr_context *ctx, rtr_scene_info *out) {
     if (!ctx || !out) return RTR_ERR_INVALID_ARGUMENT;
+    if (!ctx->ranks.empty()) ctx = ctx->ranks[0]; // every GPU holds the same scene
     RTR_LOCK(ctx);
     if (!ctx->have_scene) return RTR_ERR_NO_SCENE;
     const rtr::FlatScene &fs = ctx->flat;
@@ -732,6 +1110,7 @@ int rtr_scene_info_get(const rtr_context *ctx, rtr_scene_info *out) {
 
 int64_t rtr_bvh_leaf_order(const rtr_context *ctx, uint64_t *out, uint64_t cap) {
     if (!ctx) return RTR_ERR_INVALID_ARGUMENT;
+    if (!ctx->ranks.empty()) ctx = ctx->ranks[0];
     RTR_LOCK(ctx);
     if (!ctx->have_scene) return RTR_ERR_NO_SCENE;
     const auto &cold = ctx->flat.leaf_cold;
@@ -745,6 +1124,7 @@ int rtr_render_frame_device(rtr_context *ctx, const rtr_camera *camera, const rt
     if (!ctx) return RTR_ERR_INVALID_ARGUMENT;
     RTR_LOCK(ctx);
     if (!d_rgba8) return fail(ctx, RTR_ERR_INVALID_ARGUMENT, "null output");
+    if (ctx->multi) return multi_frame(ctx, camera, settings, width, height, seed, d_rgba8, nullptr); // (its own streams)
     return launch_frame(ctx, camera, settings, width, height, seed, 0u, 1u, nullptr, d_rgba8, nullptr, (hipStream_t)stream);
 }
 
@@ -754,6 +1134,7 @@ int rtr_render_tiles_device(rtr_context *ctx, const rtr_camera *camera, const rt
     if (!ctx) return RTR_ERR_INVALID_ARGUMENT;
     RTR_LOCK(ctx);
     if (!d_sum_rgba) return fail(ctx, RTR_ERR_INVALID_ARGUMENT, "null output");
+    if (ctx->multi) return fail(ctx, RTR_ERR_UNSUPPORTED, "a multi-GPU context shards its frames itself: use rtr_render* / rtr_render_frame_device");
     return launch_frame(ctx, camera, settings, width, height, seed, shard, n_shards, d_sum_rgba, nullptr, nullptr, (hipStream_t)stream);
 }
 
@@ -763,6 +1144,7 @@ int rtr_render_samples_device(rtr_context *ctx, const rtr_camera *camera, const 
     if (!ctx) return RTR_ERR_INVALID_ARGUMENT;
     RTR_LOCK(ctx);
     if (!d_sum_rgba) return fail(ctx, RTR_ERR_INVALID_ARGUMENT, "null output");
+    if (ctx->multi) return fail(ctx, RTR_ERR_UNSUPPORTED, "a multi-GPU context shards its frames itself: use rtr_render* / rtr_render_frame_device");
     return launch_frame(ctx, camera, settings, width, height, seed, 0u, 1u, d_sum_rgba, nullptr, nullptr, (hipStream_t)stream,
                         sample_begin, sample_count);
 }
@@ -773,6 +1155,7 @@ int rtr_resolve_device(rtr_context *ctx, const float *d_sum_rgba, uint32_t sampl
     RTR_LOCK(ctx);
     if (ctx->device < 0) return fail(ctx, RTR_ERR_NO_DEVICE, "host-only context: no HIP device bound (there is no CPU fallback)");
     if (!d_sum_rgba || width == 0 || height == 0) return fail(ctx, RTR_ERR_INVALID_ARGUMENT, "bad resolve arguments");
+    if (ctx->multi) ctx = ctx->ranks[0]; // (rank 0's device is where a multi-GPU context resolves)
     RTR_HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
     RTR_HIP_TRY(ctx, hipEventRecord(ctx->ev_res_start, s));
@@ -801,6 +1184,15 @@ int rtr_render(rtr_context *ctx, const rtr_camera *camera, const rtr_settings *s
     if (mean_rgb) {
         if ((rc = ensure_scratch(ctx, &ctx->d_mean, &ctx->mean_cap, npx * 3 * sizeof(float)))) return rc;
         dm = static_cast<float *>(ctx->d_mean);
+    }
+    if (ctx->multi) { // every GPU of the context; reduced and resolved on the first one's communication stream
+        if ((rc = multi_frame(ctx, camera, settings, width, height, seed, d8, dm))) return rc;
+        hipStream_t cs = ctx->multi->comm_stream[0];
+        RTR_HIP_TRY(ctx, hipSetDevice(ctx->device));
+        if (rgba8) RTR_HIP_TRY(ctx, hipMemcpyAsync(rgba8, d8, npx * 4, hipMemcpyDeviceToHost, cs));
+        if (mean_rgb) RTR_HIP_TRY(ctx, hipMemcpyAsync(mean_rgb, dm, npx * 3 * sizeof(float), hipMemcpyDeviceToHost, cs));
+        RTR_HIP_TRY(ctx, hipStreamSynchronize(cs));
+        return multi_sync(ctx);
     }
     rc = launch_frame(ctx, camera, settings, width, height, seed, 0u, 1u, nullptr, d8, dm, ctx->stream);
     if (rc) return rc;
@@ -834,6 +1226,20 @@ int rtr_get_stats(rtr_context *ctx, rtr_stats *out) {
     out->lds_bytes = ctx->last_lds;
     out->vgprs = ctx->last_vgprs;
     out->block_threads = 64;
+    if (ctx->multi) { // the frame's totals over the GPUs: samples and segments add up, the time is the slowest GPU's integrate
+        if (ctx->device < 0 || ctx->launches == 0) return RTR_OK;
+        if (int rc = multi_sync(ctx)) return rc;
+        for (rtr_context *rk : ctx->ranks) {
+            rtr_stats s;
+            const int rc = rtr_get_stats(rk, &s);
+            if (rc) return fail(ctx, rc, rk->error);
+            out->primary_samples += s.primary_samples;
+            out->segments += s.segments;
+            out->kernel_ms = std::max(out->kernel_ms, s.kernel_ms);
+            out->vgprs = s.vgprs; out->lds_bytes = s.lds_bytes;
+        }
+        return RTR_OK;
+    }
     if (ctx->device < 0 || ctx->launches == 0) return RTR_OK;
     RTR_HIP_TRY(ctx, hipSetDevice(ctx->device));
     RTR_HIP_TRY(ctx, hipDeviceSynchronize());
@@ -855,6 +1261,17 @@ int rtr_get_stats(rtr_context *ctx, rtr_stats *out) {
 int rtr_kernel_times_ms(rtr_context *ctx, float *out, uint32_t cap) {
     if (!ctx || !out) return RTR_ERR_INVALID_ARGUMENT;
     RTR_LOCK(ctx);
+    if (ctx->multi) { // per frame: the slowest GPU's time
+        int n = 0;
+        std::vector<float> tmp(cap ? cap : 1u);
+        for (size_t r = 0; r < ctx->ranks.size(); r++) {
+            const int k = rtr_kernel_times_ms(ctx->ranks[r], tmp.data(), cap);
+            if (k < 0) return fail(ctx, k, ctx->ranks[r]->error);
+            if (r == 0) { n = k; std::copy(tmp.begin(), tmp.begin() + k, out); }
+            else for (int i = 0; i < std::min(n, k); i++) out[n - 1 - i] = std::max(out[n - 1 - i], tmp[(size_t)(k - 1 - i)]);
+        }
+        return n;
+    }
     if (ctx->device < 0 || ctx->launches == 0) return 0;
     RTR_HIP_TRY(ctx, hipSetDevice(ctx->device));
     RTR_HIP_TRY(ctx, hipDeviceSynchronize());
@@ -873,6 +1290,17 @@ int rtr_kernel_times_ms(rtr_context *ctx, float *out, uint32_t cap) {
 int rtr_integrate_times_ms(rtr_context *ctx, float *out, uint32_t cap) {
     if (!ctx || !out) return RTR_ERR_INVALID_ARGUMENT;
     RTR_LOCK(ctx);
+    if (ctx->multi) { // per frame: the slowest GPU's time
+        int n = 0;
+        std::vector<float> tmp(cap ? cap : 1u);
+        for (size_t r = 0; r < ctx->ranks.size(); r++) {
+            const int k = rtr_integrate_times_ms(ctx->ranks[r], tmp.data(), cap);
+            if (k < 0) return fail(ctx, k, ctx->ranks[r]->error);
+            if (r == 0) { n = k; std::copy(tmp.begin(), tmp.begin() + k, out); }
+            else for (int i = 0; i < std::min(n, k); i++) out[n - 1 - i] = std::max(out[n - 1 - i], tmp[(size_t)(k - 1 - i)]);
+        }
+        return n;
+    }
     if (ctx->device < 0 || ctx->launches == 0) return 0;
     RTR_HIP_TRY(ctx, hipSetDevice(ctx->device));
     RTR_HIP_TRY(ctx, hipDeviceSynchronize());
@@ -890,6 +1318,7 @@ int rtr_integrate_times_ms(rtr_context *ctx, float *out, uint32_t cap) {
 
 const char *rtr_kernel_name(const rtr_context *ctx) {
     if (!ctx) return "";
+    if (!ctx->ranks.empty()) ctx = ctx->ranks[0];
     RTR_LOCK(ctx);
     thread_local std::string copy; // the caller's own copy: a render on another thread cannot invalidate it
     copy = ctx->kernel_name;
@@ -905,6 +1334,7 @@ int rtr_camera_ray_origin(const rtr_camera *camera, float out[12]) {
 int rtr_probe_hits(rtr_context *ctx, uint32_t enable_bvh_tree, uint64_t seed, uint32_t n_rays, const float *origins, const float *directions,
                    rtr_hit *out) {
     if (!ctx) return RTR_ERR_INVALID_ARGUMENT;
+    if (!ctx->ranks.empty()) ctx = ctx->ranks[0];
     RTR_LOCK(ctx);
     static_assert(sizeof(rtr_hit) == 48, "k_probe_hits writes 12 words per ray");
     if (ctx->device < 0) return fail(ctx, RTR_ERR_NO_DEVICE, "host-only context: no HIP device bound (there is no CPU fallback)");
@@ -934,6 +1364,7 @@ int rtr_probe_hits(rtr_context *ctx, uint32_t enable_bvh_tree, uint64_t seed, ui
 
 int rtr_selftest_sqrt(rtr_context *ctx, uint64_t *mismatches) {
     if (!ctx || !mismatches) return RTR_ERR_INVALID_ARGUMENT;
+    if (!ctx->ranks.empty()) ctx = ctx->ranks[0];
     RTR_LOCK(ctx);
     if (ctx->device < 0) return fail(ctx, RTR_ERR_NO_DEVICE, "host-only context: no HIP device bound (there is no CPU fallback)");
     RTR_HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -948,6 +1379,7 @@ int rtr_selftest_sqrt(rtr_context *ctx, uint64_t *mismatches) {
 
 int rtr_selftest_div(rtr_context *ctx, float denominator, uint32_t numerator_lo_bits, uint32_t numerator_hi_bits, uint64_t *mismatches) {
     if (!ctx || !mismatches) return RTR_ERR_INVALID_ARGUMENT;
+    if (!ctx->ranks.empty()) ctx = ctx->ranks[0];
     RTR_LOCK(ctx);
     if (ctx->device < 0) return fail(ctx, RTR_ERR_NO_DEVICE, "host-only context: no HIP device bound (there is no CPU fallback)");
     if (numerator_lo_bits > numerator_hi_bits) return fail(ctx, RTR_ERR_INVALID_ARGUMENT, "empty numerator range");
@@ -964,6 +1396,17 @@ int rtr_selftest_div(rtr_context *ctx, float denominator, uint32_t numerator_lo_
 int rtr_segment_counts(rtr_context *ctx, uint64_t *out, uint32_t cap) {
     if (!ctx || !out) return RTR_ERR_INVALID_ARGUMENT;
     RTR_LOCK(ctx);
+    if (ctx->multi) { // per frame: the GPUs' segments added up
+        int n = 0;
+        std::vector<uint64_t> tmp(cap ? cap : 1u);
+        for (size_t r = 0; r < ctx->ranks.size(); r++) {
+            const int k = rtr_segment_counts(ctx->ranks[r], tmp.data(), cap);
+            if (k < 0) return fail(ctx, k, ctx->ranks[r]->error);
+            if (r == 0) { n = k; std::copy(tmp.begin(), tmp.begin() + k, out); }
+            else for (int i = 0; i < std::min(n, k); i++) out[n - 1 - i] += tmp[(size_t)(k - 1 - i)];
+        }
+        return n;
+    }
     if (ctx->device < 0 || ctx->launches == 0) return 0;
     RTR_HIP_TRY(ctx, hipSetDevice(ctx->device));
     RTR_HIP_TRY(ctx, hipDeviceSynchronize());

@@ -1429,13 +1429,14 @@ RTR_DEV void ticket_end(uint32_t id, uint32_t lane, uint32_t pixel, V3 acc) {
 // One lane = one pixel of the workgroup's ticket.  LDS (dynamic, 16-byte aligned pieces):
 //   [chain: max_depth x 64 u32][stack refs: cap x 64][stack t: cap x 64][spheres: NS x 8][materials: lds_mats x 8]
 template <uint32_t WORLD, uint32_t NS, uint32_t VOL, bool MESH>
-// 96 scalar registers: a wave's SGPRs come in 16-register granules out of 800 per SIMD, so the 105 the compiler would
-// take (sphere constants + camera + parameters) admit 7 waves per SIMD and 96 admit 8 -- the vector registers (62)
-// already allow 8.  Measured +2.4 % on the headline kernel, neutral on the tree kernels.
-__attribute__((amdgpu_num_sgpr(96)))
-// (the sphere world at a 7-wave register budget: the compiler would take 77 VGPRs unasked -- 6 waves, 15.4 ms on the
-// headline frame -- and fits 65 without spilling when told to -- 7 waves, 14.7 ms; 8: 64 VGPRs with 51 spilled SGPRs, 14.8 ms)
-__global__ __launch_bounds__(64, WORLD == WORLD_LINEAR_SPHERES ? 7 : 1) void k_render(const RenderParams p) {
+// Register budget of the sphere world with up to five spheres in scalar registers (the headline): 8 waves per SIMD -- 64
+// vector registers, and 80 scalar ones (a wave's SGPRs come in 16-register granules out of 800 per SIMD: 96 admit 7
+// waves, 80 admit 8).  Round 2 could not afford it (64 VGPRs only with 51 spilled SGPRs: 14.8 ms against 14.05 at 7 waves);
+// with the per-ticket parameters read through the kernarg pointer the 8-wave build spills 13 SGPRs, none in the segment
+// loop: 13.79 ms against 13.95 at 7 waves.  More spheres in registers, the generic sphere loop and the tree worlds keep
+// the 7-wave / 96-SGPR budget (unasked the compiler takes 77 VGPRs = 6 waves: 15.4 ms on the headline frame).
+__attribute__((amdgpu_num_sgpr(96))) // (the cap of the 7-wave instantiations; an 8-wave launch bound implies 80)
+__global__ __launch_bounds__(64, WORLD == WORLD_LINEAR_SPHERES ? (NS >= 1u && NS <= 5u ? 8 : 7) : 1) void k_render(const RenderParams p) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const uint32_t lane = threadIdx.x;
 #ifdef RTR_X_LANESTAT
@@ -2091,6 +2092,23 @@ __global__ __launch_bounds__(256) void k_resolve(const float *sum_rgba, uint32_t
     if (i >= n_pixels) return;
     const float4 s = reinterpret_cast<const float4 *>(sum_rgba)[i];
     store_pixel(mk(s.x, s.y, s.z), spp, i, nullptr, rgba8, mean_rgb);
+}
+
+// rtr_create_multi with every rank on ONE device (a test configuration: RCCL cannot put two ranks on one GPU): the ranks'
+// float4 partial sums added in rank order -- what ncclReduce does across GPUs.
+__global__ __launch_bounds__(256) void k_sum_partials(const float *const *partials, uint32_t n, uint32_t n_pixels, float *total) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pixels) return;
+    float4 acc = reinterpret_cast<const float4 *>(partials[0])[i];
+    for (uint32_t r = 1; r < n; r++) {
+        const float4 v = reinterpret_cast<const float4 *>(partials[r])[i];
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    reinterpret_cast<float4 *>(total)[i] = acc;
+}
+hipError_t launch_sum_partials(const float *const *d_partials, uint32_t n, uint32_t n_pixels, float *d_total, hipStream_t stream) {
+    hipLaunchKernelGGL(k_sum_partials, dim3((n_pixels + 255u) / 256u), dim3(256), 0, stream, d_partials, n, n_pixels, d_total);
+    return hipGetLastError();
 }
 
 // rtr_probe_hits: world.hit (render.rs:38: tmin = 0.00001, tmax = +inf) for caller-supplied rays, one lane per ray, through

@@ -71,10 +71,16 @@ class Renderer:
     """One rtr_context bound to one GPU (device >= 0) or host-only (device = -1: scene lowering + BVH
     introspection only; rendering raises RTR_ERR_NO_DEVICE -- there is no CPU fallback)."""
 
-    def __init__(self, device: int = 0):
+    def __init__(self, device=0):
+        """`device`: a GPU index, -1 (host-only), or a sequence of GPU indices -- one context over several GPUs of this
+        node (rtr_create_multi: frames are divided among them and reduced with RCCL inside the library)."""
         self._lib = _capi.load()
         self._ctx = C.c_void_p()
-        rc = self._lib.rtr_create(int(device), C.byref(self._ctx))
+        if isinstance(device, (list, tuple)):
+            ids = (C.c_int * len(device))(*[int(d) for d in device])
+            rc = self._lib.rtr_create_multi(ids, len(device), C.byref(self._ctx))
+        else:
+            rc = self._lib.rtr_create(int(device), C.byref(self._ctx))
         if rc != _capi.RTR_OK:
             raise _capi.RtrError(rc, (self._lib.rtr_last_error(None) or b"").decode())
         self.device = device

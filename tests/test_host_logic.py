@@ -313,3 +313,50 @@ def test_render_target_writes_png_and_ppm(tmp_path):
     t.save(str(tmp_path / "a.ppm"))
     np.testing.assert_array_equal(read_png(str(tmp_path / "a.png")), t.image())
     np.testing.assert_array_equal(read_ppm(str(tmp_path / "a.ppm")), t.image()[:, :, :3])
+
+
+def test_multi_gpu_sample_split_is_a_partition():
+    """rtr_create_multi's sample split (the library's own arithmetic, rtr_sample_range): the ranks' ranges are contiguous,
+    disjoint and cover the frame's samples; equal to the Python driver's (raytracingrust_amd/distributed.py)."""
+    from raytracingrust_amd.distributed import sample_range
+
+    L = _capi.load()
+    for n in (1, 2, 3, 7, 8, 64):
+        for spp in (0, 1, 5, 63, 256, 257, 1024):
+            end = 0
+            for r in range(n):
+                b, c = C.c_uint32(), C.c_uint32()
+                assert L.rtr_sample_range(r, n, spp, C.byref(b), C.byref(c)) == 0
+                assert (b.value, c.value) == tuple(sample_range(r, n, spp))
+                assert b.value == end and c.value in (spp // n, spp // n + 1)
+                end += c.value
+            assert end == spp
+    b, c = C.c_uint32(), C.c_uint32()
+    assert L.rtr_sample_range(2, 2, 8, C.byref(b), C.byref(c)) == -1  # rank out of range
+    assert L.rtr_sample_range(0, 0, 8, C.byref(b), C.byref(c)) == -1
+
+
+def test_host_only_multi_context():
+    """A context over several (host-only) ranks lowers and flattens the scene once and answers the introspection calls;
+    every compute call fails with RTR_ERR_NO_DEVICE; mixed or repeated-and-mixed device lists are rejected."""
+    with rt.Renderer([-1, -1, -1]) as r:
+        r.upload_scene(simple_scene(2))
+        with rt.Renderer(-1) as single:
+            single.upload_scene(simple_scene(2))
+            assert np.array_equal(r.bvh_leaf_order(), single.bvh_leaf_order())
+            assert r.scene_info().n_leaves == single.scene_info().n_leaves == 102
+        with pytest.raises(rt.RtrError) as e:
+            r.render(8, 8)
+        assert e.value.code == -2
+        with pytest.raises(rt.RtrError) as e:
+            r.render_samples_device(8, 8, 1, 0, 1, 0x1000)
+        assert e.value.code == -8  # a multi-GPU context shards its frames itself
+        r.set_option("multi_split", "tiles")
+        with pytest.raises(rt.RtrError):
+            r.set_option("multi_split", "rows")
+    with rt.Renderer(-1) as single:
+        with pytest.raises(rt.RtrError):
+            single.set_option("multi_split", "tiles")
+    for bad in ([0, -1], [0, 1, 0], []):
+        with pytest.raises(rt.RtrError):
+            rt.Renderer(bad)
