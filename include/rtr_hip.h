@@ -182,6 +182,13 @@ typedef struct rtr_stats {
     double upload_ms;         /* host build + flatten + copy of the last rtr_upload_scene (wall) */
     uint32_t launches;        /* render kernels launched by this context so far */
     uint32_t vgprs, lds_bytes, block_threads; /* launch configuration of the last render kernel */
+    /* ABI revision 5 -- traversal work of the last render, counted on the device when option "traversal_counters" is on and
+     * the launch walked the tree (traversal_counted = 1; else all zero).  node_steps: BvhNode::Split visits -- a node step
+     * tests the boxes of BOTH children (bvh.rs:160-166 / aabb.rs:81-137), so the reference's count of AABB::hit calls under
+     * its unculled both-children traversal compares with 2 * node_steps; leaf_tests: Sphere::hit / Triangle::hit /
+     * Volume::hit calls reached through the tree; sky_lookups: SkyMap::sample calls (backgrounds.rs:84-92). */
+    uint64_t node_steps, leaf_tests, sky_lookups;
+    uint32_t traversal_counted, reserved;
 } rtr_stats;
 
 typedef struct rtr_context rtr_context;
@@ -246,7 +253,11 @@ int rtr_abi_version(void);
  *                 them: bit-identical frames.  "auto": trees of 32 leaves or more
  *                 take "samples" (inside tile-sharded launches, where it does not apply: "resumable" for scenes with
  *                 meshes, else "wave"); smaller trees "wave". */
-/*   "multi_split" = "samples" (default) | "tiles" (contexts of rtr_create_multi; applied at the next render): see there. */
+/*   "traversal_counters" = "off" (default) | "on" (applied at the next render): tree launches take the counting instantiation
+ *                 of the "samples" kernel (the same walk; its lanes also add up their node steps, leaf tests and SkyMap lookups)
+ *                 and rtr_get_stats reports them -- how much of the reference's unculled traversal the ordered, culling walk
+ *                 skips.  Costs a few per cent; the frame is unchanged.
+ *   "multi_split" = "samples" (default) | "tiles" (contexts of rtr_create_multi; applied at the next render): see there. */
 /*   "samples_batch" = "0" (default: what half of the free device memory holds, at most 16 GiB of radiance and 64
  *                 samples for "stream") | N: samples per batch of the "samples" / "stream" kernels' buffers; a pixel's
  *                 running sum is carried from batch to batch, so any N gives the same frame.  A batch whose allocation

@@ -68,7 +68,9 @@ class rtr_scene_info(C.Structure):
 class rtr_stats(C.Structure):
     _fields_ = [("primary_samples", C.c_uint64), ("segments", C.c_uint64), ("kernel_ms", C.c_double),
                 ("resolve_ms", C.c_double), ("upload_ms", C.c_double), ("launches", C.c_uint32),
-                ("vgprs", C.c_uint32), ("lds_bytes", C.c_uint32), ("block_threads", C.c_uint32)]
+                ("vgprs", C.c_uint32), ("lds_bytes", C.c_uint32), ("block_threads", C.c_uint32),
+                ("node_steps", C.c_uint64), ("leaf_tests", C.c_uint64), ("sky_lookups", C.c_uint64),
+                ("traversal_counted", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class rtr_hit(C.Structure):

@@ -77,6 +77,8 @@ struct rtr_context {
     uint32_t debug_lds_pad = 0; // option "debug_lds_pad"
     uint32_t block_samples = 8; // option "block_samples": samples of one tile a wave of the samples kernel claims at a time
     uint32_t *d_work = nullptr; // the integrate kernels' ticket counter (one word, zeroed before every launch)
+    bool traversal_counters = false; // option "traversal_counters": tree launches take the counting samples kernel
+    bool last_counted = false;       // the most recent launch filled d_work[8 ..]: node steps, leaf tests, SkyMap lookups
     bool stack_wide = false;    // option "stack_entries" = "wide"
     uint32_t wf_flush = 8; // option "stream_flush": finished walks a wave of k_wf_intersect collects before storing them
     void *d_wf = nullptr;  // streaming wavefront: the path records of one batch (ray, hit, state, chain, stage)
@@ -270,8 +272,8 @@ int launch_frame(rtr_context *ctx, const rtr_camera *camera, const rtr_settings 
     // their cheap samples (5-sphere tree -13 %; 102 spheres +8 % at 1080p, +1 % at 4K; meshes +20 %).
     const bool per_sample_ok = st->enable_bvh_tree && p.max_depth > 0u && sample_count > 0u && n_shards == 1u;
     // "stream": path state in HBM, one kernel per stage and depth (rtr_kernels.hip "streaming wavefront"); same conditions
-    const bool streaming = ctx->tree_kernel == 4 && per_sample_ok;
-    p.sample_parallel = ((ctx->tree_kernel == 3 || (ctx->tree_kernel == 0 && fs.leaf_hot.size() >= 32u)) && per_sample_ok) ? 1u : 0u;
+    const bool streaming = ctx->tree_kernel == 4 && per_sample_ok && !ctx->traversal_counters;
+    p.sample_parallel = ((ctx->tree_kernel == 3 || (ctx->tree_kernel == 0 && fs.leaf_hot.size() >= 32u) || ctx->traversal_counters) && per_sample_ok) ? 1u : 0u;
     if ((ctx->tree_kernel == 3 || ctx->tree_kernel == 4) && !p.sample_parallel && !streaming) p.resumable_walk = 1u;
     if (streaming) p.sample_parallel = 1u; // shares the per-sample radiance buffer and k_sum_samples with "samples"
     p.tiles_x = (width + 7u) / 8u;
@@ -416,6 +418,11 @@ int launch_frame(rtr_context *ctx, const rtr_camera *camera, const rtr_settings 
         RTR_HIP_TRY(ctx, hipMemsetAsync(ctx->d_chunk_flags, 0, (size_t)grid * sizeof(uint32_t), stream));
     }
     RTR_HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters + slot, 0, sizeof(unsigned long long), stream));
+    ctx->last_counted = ctx->traversal_counters && p.sample_parallel && !streaming && grid > 0;
+    if (ctx->last_counted) { // the counting instantiation of the samples kernel adds into three words behind the ticket counter
+        p.walk_counters = reinterpret_cast<unsigned long long *>(ctx->d_work) + 1;
+        RTR_HIP_TRY(ctx, hipMemsetAsync(p.walk_counters, 0, 3 * sizeof(unsigned long long), stream));
+    }
     RTR_HIP_TRY(ctx, hipEventRecord(ctx->ev_start[slot], stream));
     if (grid > 0 && !p.sample_parallel) {
         // One workgroup (one wave) per ticket -- (chunk, tile), chunk-major; a workgroup claims its ticket from the counter
@@ -731,6 +738,7 @@ int multi_frame(rtr_context *ctx, const rtr_camera *camera, const rtr_settings *
         rk->tree_kernel = ctx->tree_kernel; rk->sample_chunks = ctx->sample_chunks; rk->block_samples = ctx->block_samples;
         rk->samples_batch = ctx->samples_batch; rk->stack_wide = ctx->stack_wide; rk->sky_bilinear = ctx->sky_bilinear;
         rk->chunk_timeout_s = ctx->chunk_timeout_s; rk->wf_flush = ctx->wf_flush; rk->debug_fault = ctx->debug_fault;
+        rk->traversal_counters = ctx->traversal_counters;
         m.workers[r]->post([&m, ctx, rk, r, n, buf, reuse, tiles, cam, settings, width, height, seed, bytes, d_rgba8, d_mean_rgb] {
             std::lock_guard<std::recursive_mutex> g(rk->mu);
             int &out = m.rank_rc[r];
@@ -1084,6 +1092,12 @@ int rtr_set_option(rtr_context *ctx, const char *name, const char *value) {
         else return fail(ctx, RTR_ERR_INVALID_ARGUMENT, "multi_split must be \"samples\" or \"tiles\"");
         return RTR_OK;
     }
+    if (n == "traversal_counters") { // takes effect at the next render
+        if (v == "on") ctx->traversal_counters = true;
+        else if (v == "off") ctx->traversal_counters = false;
+        else return fail(ctx, RTR_ERR_INVALID_ARGUMENT, "traversal_counters must be \"on\" or \"off\"");
+        return RTR_OK;
+    }
     if (n == "leaf_pairs") {
         if (v == "on") ctx->build_options.leaf_pairs = true;
         else if (v == "off") ctx->build_options.leaf_pairs = false;
@@ -1237,6 +1251,8 @@ int rtr_get_stats(rtr_context *ctx, rtr_stats *out) {
             out->segments += s.segments;
             out->kernel_ms = std::max(out->kernel_ms, s.kernel_ms);
             out->vgprs = s.vgprs; out->lds_bytes = s.lds_bytes;
+            out->node_steps += s.node_steps; out->leaf_tests += s.leaf_tests; out->sky_lookups += s.sky_lookups;
+            out->traversal_counted = s.traversal_counted;
         }
         return RTR_OK;
     }
@@ -1255,6 +1271,12 @@ int rtr_get_stats(rtr_context *ctx, rtr_stats *out) {
     unsigned long long seg = 0;
     RTR_HIP_TRY(ctx, hipMemcpy(&seg, ctx->d_counters + slot, sizeof seg, hipMemcpyDeviceToHost));
     out->segments = seg;
+    if (ctx->last_counted) {
+        unsigned long long w[3] = {0, 0, 0};
+        RTR_HIP_TRY(ctx, hipMemcpy(w, reinterpret_cast<unsigned long long *>(ctx->d_work) + 1, sizeof w, hipMemcpyDeviceToHost));
+        out->node_steps = w[0]; out->leaf_tests = w[1]; out->sky_lookups = w[2];
+        out->traversal_counted = 1u;
+    }
     return RTR_OK;
 }
 

@@ -148,6 +148,7 @@ struct RenderParams {
     uint8_t *rgba8;              // fused path or nullptr
     float *mean_rgb;             // fused path, optional
     unsigned long long *counter; // segments
+    unsigned long long *walk_counters; // option "traversal_counters": node steps, leaf tests, SkyMap lookups of the launch (3 words), or nullptr
 };
 
 } // namespace rtr

@@ -458,10 +458,12 @@ typedef uint16_t StackT;
 RTR_DEV StackT stack_t_pack(float e) { return (StackT)(__float_as_uint(e) >> 16); }
 RTR_DEV float stack_t_unpack(StackT h) { return __uint_as_float((uint32_t)h << 16); }
 
+// The walk's best hit so far.  Two registers: the barycentrics of a winning triangle are re-derived once, in finish_leaf,
+// from the same operands by the same operations (round 2 carried u, v and the cull bound through every trip; the tree
+// kernels live at the edge of their register budget -- DESIGN.md section 5.2).
 struct Best {
-    float t, u, v;
+    float t;       // +inf until a leaf is hit
     uint32_t leaf; // REF_LEAF|type|L, or REF_NONE
-    float cull;    // boxes entered beyond this distance are skipped: t * kCullMargin (+inf until a leaf is hit)
 };
 // The reference visits every box the ray pierces (bvh.rs:160-166); the walk here skips a box whose entry distance lies
 // beyond the best hit so far.  Entry distances and hit distances are rounded results of different formulas, so a
@@ -472,11 +474,15 @@ struct Best {
 // oracle's unculled recursive traversal (tests/test_gpu_parity.py); without it 0-20 pixels per 1080p frame differed in
 // the last bit.  Cost of the margin: below measurement noise.
 constexpr float kCullMargin = 1.0009765625f; // 1 + 2^-10
-RTR_DEV void best_reset(Best &b) { b.leaf = REF_NONE; b.t = __builtin_inff(); b.u = 0.0f; b.v = 0.0f; b.cull = __builtin_inff(); }
-RTR_DEV void best_take(Best &b, float t, float u, float v, uint32_t leaf) {
-    b.t = t; b.u = u; b.v = v; b.leaf = leaf;
-    b.cull = t * kCullMargin; // t > 0 (every accepted t exceeds tmin); a NaN t gives a NaN bound: nothing is culled
-}
+RTR_DEV void best_reset(Best &b) { b.leaf = REF_NONE; b.t = __builtin_inff(); }
+RTR_DEV void best_take(Best &b, float t, uint32_t leaf) { b.t = t; b.leaf = leaf; }
+// boxes entered beyond this distance are skipped: +inf until a leaf is hit; t > 0 (every accepted t exceeds tmin); a NaN t
+// gives a NaN bound: nothing is culled
+RTR_DEV float best_cull(const Best &b) { return b.t * kCullMargin; }
+
+// Traversal counters of a lane (rtr_stats node_steps / leaf_tests / sky_lookups, option "traversal_counters"): incremented
+// where the walk does the work; dead code -- and removed by the compiler -- in every kernel that does not store them.
+struct WalkCounts { uint32_t nodes = 0u, leaves = 0u, sky = 0u; };
 
 // Candidate acceptance inside one tree: the reference merges with `left < right ? left : right`
 // (bvh.rs:181-186): the smaller t wins, and the right operand -- the later leaf in depth-first order -- wins whenever
@@ -521,7 +527,7 @@ RTR_DEV void test_leaf(const RenderParams &p, uint32_t ref, const Ray &r, V3 inv
         // (Möller-Trumbore without its early exits -- all four tests on every lane -- was measured neutral.)
         if (triangle_t(mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y), mk(q1.z, q1.w, q2x), r, t, u, v) &&
             accept_tree(best, t, ref)) {
-            best_take(best, t, u, v, ref);
+            best_take(best, t, ref);
         }
     } else if (VOL && (ref & REF_VOL)) {
         const float4 q0 = hot[0], q1 = hot[1], q2 = hot[2];
@@ -529,7 +535,7 @@ RTR_DEV void test_leaf(const RenderParams &p, uint32_t ref, const Ray &r, V3 inv
         float t;
         // Volume::hit(ray, tmin, +inf) as called from the tree (bvh.rs:156)
         if (volume_leaf_t<VOL>(p, q0, q1, q2, r, inv, a, __builtin_inff(), rng, stk_ref, sp, lane, t) && accept_tree(best, t, ref)) {
-            best_take(best, t, best.u, best.v, ref);
+            best_take(best, t, ref);
         }
     } else {
         const float4 q0 = hot[0]; // centre, radius
@@ -538,7 +544,7 @@ RTR_DEV void test_leaf(const RenderParams &p, uint32_t ref, const Ray &r, V3 inv
         float t;
         // Sphere::hit(ray, tmin, +inf) as called from the tree (bvh.rs:156)
         if (sphere_t(mk(q0.x, q0.y, q0.z), r2, r, a, __builtin_inff(), t) && accept_tree(best, t, ref)) {
-            best_take(best, t, best.u, best.v, ref);
+            best_take(best, t, ref);
         }
     }
 }
@@ -568,6 +574,67 @@ __device__ __forceinline__ bool lane_of(uint64_t mask) { return __builtin_amdgcn
 // triangles of a pair in one 96-byte gather, +13 VGPRs and no faster; an explicit bound test on the push, -1 ... -4 %:
 // one push per node record on the path, sp <= tree height < p.stack_cap by construction of the flattener, checked on the
 // host by tests/cpp/scene_sanity.cpp.)
+// The node step of a trip: both children's boxes (q0_ .. q2_ and the refs / flags in q3_: one DevNode record) against the
+// ray, the nearer child taken, the other deferred on the lane's stack; sets pop_ when neither is entered.
+#define RTR_NODE_STEP(RAY, TMAX_BOX, q0_, q1_, q2_, q3_)                                                                   \
+    {                                                                                                                    \
+        counts.nodes++;                                                                                                  \
+        float lmin_[3] = {q0_.x, q0_.y, q0_.z}, lmax_[3] = {q0_.w, q1_.x, q1_.y};                                    \
+        float rmin_[3] = {q1_.z, q1_.w, q2_.x}, rmax_[3] = {q2_.y, q2_.z, q2_.w};                                    \
+        const uint32_t l_ = __float_as_uint(q3_.x), r_ = __float_as_uint(q3_.y);                                     \
+        const uint32_t flags_ = __float_as_uint(q3_.z);                                                              \
+        const bool lvol_ = VOL && (flags_ & NODE_LVOL), rvol_ = VOL && (flags_ & NODE_RVOL);                         \
+        bool hl_ = l_ != REF_NONE, hr_ = r_ != REF_NONE;                                                             \
+        float el_ = 0.0f, er_ = 0.0f;                                                                                \
+        if constexpr (MESH) {                                                                                        \
+            /* Mesh scenes: nearly every child is a Split node or a leaf pair, i.e. carries a box.  Both slab tests */ \
+            /* run unconditionally, side by side -- straight-line code instead of two exec-mask regions            */ \
+            /* (+2 ... +8 % on C3/C4; on sphere scenes, where half the children are bare leaves, it loses 4 %).    */ \
+            float tl_, tr_;                                                                                          \
+            const bool sl_ = slab(lmin_, lmax_, RAY, inv, TMAX_BOX, tl_);                                            \
+            const bool sr_ = slab(rmin_, rmax_, RAY, inv, TMAX_BOX, tr_);                                            \
+            const bool gl_ = (l_ & (REF_LEAF | REF_PAIR)) != REF_LEAF; /* Split nodes and leaf pairs carry a box */  \
+            const bool gr_ = (r_ & (REF_LEAF | REF_PAIR)) != REF_LEAF;                                               \
+            el_ = gl_ ? tl_ : 0.0f;                                                                                  \
+            er_ = gr_ ? tr_ : 0.0f;                                                                                  \
+            /* hl = nonempty && (!boxed || (slab && (vol || !(t > cull)))), cull being +inf until a leaf is hit --   */ \
+            /* combined as wave masks in scalar registers: written on bools the compiler turns the expression into   */ \
+            /* selects of 0/1 vectors (five vector instructions per child, ten per node step).                       */ \
+            hl_ = lane_of(wave_mask(hl_) & (~wave_mask(gl_) | (wave_mask(sl_) & (wave_mask(lvol_) | ~wave_mask(tl_ > best_cull(best)))))); \
+            hr_ = lane_of(wave_mask(hr_) & (~wave_mask(gr_) | (wave_mask(sr_) & (wave_mask(rvol_) | ~wave_mask(tr_ > best_cull(best)))))); \
+        } else {                                                                                                     \
+            if (hl_ && (l_ & (REF_LEAF | REF_PAIR)) != REF_LEAF) {                                                   \
+                hl_ = slab(lmin_, lmax_, RAY, inv, TMAX_BOX, el_);                                                   \
+                if (!lvol_ && el_ > best_cull(best)) hl_ = false;                                                        \
+            }                                                                                                        \
+            if (hr_ && (r_ & (REF_LEAF | REF_PAIR)) != REF_LEAF) {                                                   \
+                hr_ = slab(rmin_, rmax_, RAY, inv, TMAX_BOX, er_);                                                   \
+                if (!rvol_ && er_ > best_cull(best)) hr_ = false;                                                        \
+            }                                                                                                        \
+        }                                                                                                            \
+        RTR_LS(14, hl_ && hr_)                                                                                       \
+        if (hl_ && hr_) {                                                                                            \
+            bool sw_ = er_ < el_;                                                                                    \
+            if (lvol_ && rvol_) sw_ = false; /* both subtrees draw: keep the reference's left-then-right order */    \
+            const uint32_t second_ = sw_ ? l_ : r_;                                                                  \
+            float esecond_ = sw_ ? el_ : er_;                                                                        \
+            if (sw_ ? lvol_ : rvol_) esecond_ = 0.0f; /* never culled at pop time: no bound is below tmin */        \
+            cur = sw_ ? r_ : l_;                                                                                     \
+            if constexpr (stack_packed) {                                                                            \
+                stk_ref[sp * 64 + lane] = stack_pack32(second_, esecond_);                                           \
+            } else {                                                                                                 \
+                stk_ref[sp * 64 + lane] = second_;                                                                   \
+                stk_t[sp * 64 + lane] = stack_t_pack(esecond_);                                                      \
+            }                                                                                                        \
+            sp++;                                                                                                    \
+        } else if (hl_) {                                                                                            \
+            cur = l_;                                                                                                \
+        } else if (hr_) {                                                                                            \
+            cur = r_;                                                                                                \
+        } else {                                                                                                     \
+            pop_ = true;                                                                                             \
+        }                                                                                                            \
+    }
 #define RTR_WALK_TRIP(RAY, TMAX_BOX, ON_EMPTY)                                                                           \
     {                                                                                                                    \
         RTR_LS1(1) RTR_LS(2, true)                                                                                       \
@@ -588,61 +655,7 @@ __device__ __forceinline__ bool lane_of(uint64_t mask) { return __builtin_amdgcn
                 gather_fence(q0_, q1_, q2_, refs_);                                                                      \
                 q3_ = make_float4(refs_.x, refs_.y, 0.0f, 0.0f);                                                         \
             }                                                                                                            \
-            float lmin_[3] = {q0_.x, q0_.y, q0_.z}, lmax_[3] = {q0_.w, q1_.x, q1_.y};                                    \
-            float rmin_[3] = {q1_.z, q1_.w, q2_.x}, rmax_[3] = {q2_.y, q2_.z, q2_.w};                                    \
-            const uint32_t l_ = __float_as_uint(q3_.x), r_ = __float_as_uint(q3_.y);                                     \
-            const uint32_t flags_ = __float_as_uint(q3_.z);                                                              \
-            const bool lvol_ = VOL && (flags_ & NODE_LVOL), rvol_ = VOL && (flags_ & NODE_RVOL);                         \
-            bool hl_ = l_ != REF_NONE, hr_ = r_ != REF_NONE;                                                             \
-            float el_ = 0.0f, er_ = 0.0f;                                                                                \
-            if constexpr (MESH) {                                                                                        \
-                /* Mesh scenes: nearly every child is a Split node or a leaf pair, i.e. carries a box.  Both slab tests */ \
-                /* run unconditionally, side by side -- straight-line code instead of two exec-mask regions            */ \
-                /* (+2 ... +8 % on C3/C4; on sphere scenes, where half the children are bare leaves, it loses 4 %).    */ \
-                float tl_, tr_;                                                                                          \
-                const bool sl_ = slab(lmin_, lmax_, RAY, inv, TMAX_BOX, tl_);                                            \
-                const bool sr_ = slab(rmin_, rmax_, RAY, inv, TMAX_BOX, tr_);                                            \
-                const bool gl_ = (l_ & (REF_LEAF | REF_PAIR)) != REF_LEAF; /* Split nodes and leaf pairs carry a box */  \
-                const bool gr_ = (r_ & (REF_LEAF | REF_PAIR)) != REF_LEAF;                                               \
-                el_ = gl_ ? tl_ : 0.0f;                                                                                  \
-                er_ = gr_ ? tr_ : 0.0f;                                                                                  \
-                /* hl = nonempty && (!boxed || (slab && (vol || !(t > cull)))), cull being +inf until a leaf is hit --   */ \
-                /* combined as wave masks in scalar registers: written on bools the compiler turns the expression into   */ \
-                /* selects of 0/1 vectors (five vector instructions per child, ten per node step).                       */ \
-                hl_ = lane_of(wave_mask(hl_) & (~wave_mask(gl_) | (wave_mask(sl_) & (wave_mask(lvol_) | ~wave_mask(tl_ > best.cull))))); \
-                hr_ = lane_of(wave_mask(hr_) & (~wave_mask(gr_) | (wave_mask(sr_) & (wave_mask(rvol_) | ~wave_mask(tr_ > best.cull))))); \
-            } else {                                                                                                     \
-                if (hl_ && (l_ & (REF_LEAF | REF_PAIR)) != REF_LEAF) {                                                   \
-                    hl_ = slab(lmin_, lmax_, RAY, inv, TMAX_BOX, el_);                                                   \
-                    if (!lvol_ && el_ > best.cull) hl_ = false;                                                          \
-                }                                                                                                        \
-                if (hr_ && (r_ & (REF_LEAF | REF_PAIR)) != REF_LEAF) {                                                   \
-                    hr_ = slab(rmin_, rmax_, RAY, inv, TMAX_BOX, er_);                                                   \
-                    if (!rvol_ && er_ > best.cull) hr_ = false;                                                          \
-                }                                                                                                        \
-            }                                                                                                            \
-            RTR_LS(14, hl_ && hr_)                                                                                       \
-            if (hl_ && hr_) {                                                                                            \
-                bool sw_ = er_ < el_;                                                                                    \
-                if (lvol_ && rvol_) sw_ = false; /* both subtrees draw: keep the reference's left-then-right order */    \
-                const uint32_t second_ = sw_ ? l_ : r_;                                                                  \
-                float esecond_ = sw_ ? el_ : er_;                                                                        \
-                if (sw_ ? lvol_ : rvol_) esecond_ = 0.0f; /* never culled at pop time: no bound is below tmin */        \
-                cur = sw_ ? r_ : l_;                                                                                     \
-                if constexpr (stack_packed) {                                                                            \
-                    stk_ref[sp * 64 + lane] = stack_pack32(second_, esecond_);                                           \
-                } else {                                                                                                 \
-                    stk_ref[sp * 64 + lane] = second_;                                                                   \
-                    stk_t[sp * 64 + lane] = stack_t_pack(esecond_);                                                      \
-                }                                                                                                        \
-                sp++;                                                                                                    \
-            } else if (hl_) {                                                                                            \
-                cur = l_;                                                                                                \
-            } else if (hr_) {                                                                                            \
-                cur = r_;                                                                                                \
-            } else {                                                                                                     \
-                pop_ = true;                                                                                             \
-            }                                                                                                            \
+            RTR_NODE_STEP(RAY, TMAX_BOX, q0_, q1_, q2_, q3_)                                                             \
         }                                                                                                                \
         /* A lane whose node step has just descended into a leaf tests it in the same trip (and so does a lane that stood */ \
         /* at a leaf when the trip began): a leaf visit costs no trip of its own.  Same operations per lane in the same  */ \
@@ -650,6 +663,7 @@ __device__ __forceinline__ bool lane_of(uint64_t mask) { return __builtin_amdgcn
         if (!pop_ && (cur & REF_LEAF)) {                                                                                             \
             RTR_LS1(4) RTR_LS(3, true)                                                                                   \
             /* a REF_PAIR ref stands for Split(leaf L, leaf L+1), its box already tested where the ref was read */       \
+            counts.leaves++;                                                                                             \
             test_leaf<VOL>(p, cur & ~REF_PAIR, RAY, inv, a, best, rng, stk_ref, sp, lane);                               \
             pop_ = !(cur & REF_PAIR);                                                                                    \
             cur = (cur & ~REF_PAIR) + 1u;                                                                                \
@@ -664,7 +678,7 @@ __device__ __forceinline__ bool lane_of(uint64_t mask) { return __builtin_amdgcn
                 float e_;                                                                                                \
                 if constexpr (stack_packed) { e_ = stack_t32(c_); c_ = stack_ref32(c_); }                                \
                 else e_ = stack_t_unpack(stk_t[sp * 64 + lane]);                                                         \
-                if (e_ > best.cull) continue; /* its box is entered beyond the best hit (never for 0 entries) */         \
+                if (e_ > best_cull(best)) continue; /* its box is entered beyond the best hit (never for 0 entries) */   \
                 cur = c_;                                                                                                \
                 got_ = true;                                                                                             \
                 break;                                                                                                   \
@@ -682,6 +696,7 @@ RTR_DEV void traverse(const RenderParams &p, uint32_t root, const Ray &r, V3 inv
     uint32_t cur = root;
     bool walking = true;
     constexpr bool stack_packed = false;
+    WalkCounts counts;
     while (walking) RTR_WALK_TRIP(r, tmax_box, walking = false)
 }
 
@@ -711,7 +726,13 @@ RTR_DEV void finish_leaf(const RenderParams &p, const Best &best, const Ray &r, 
     if (best.leaf & REF_TRI) {
         float4 c1 = cold[1], c2 = cold[2], c3 = cold[3];
         V3 n0 = mk(c0.x, c0.y, c0.z), n1 = mk(c1.x, c1.y, c1.z), n2 = mk(c2.x, c2.y, c2.z), fn = mk(c3.x, c3.y, c3.z);
-        float u = best.u, v = best.v;
+        // the winner's barycentrics (mesh.rs:163-184), by Triangle::hit's own operations on its own operands: the values the
+        // walk computed when it accepted this triangle
+        const float4 *hot = reinterpret_cast<const float4 *>(p.leaf_hot + L);
+        const float4 q0 = hot[0], q1 = hot[1];
+        const float q2x = reinterpret_cast<const float *>(hot)[8];
+        float tt, u, v;
+        (void)triangle_t(mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y), mk(q1.z, q1.w, q2x), r, tt, u, v);
         V3 n = add(add(scale(n1, u), scale(n2, v)), scale(n0, 1.0f - u - v));
         // mesh.rs:187: normal.angle(face) > 0 with cgmath angle = atan2(|n x f|, n.f)
         V3 cr = cross(n, fn);
@@ -878,7 +899,7 @@ RTR_DEV bool world_hit(const RenderParams &p, const Ray &r, Hit &h, uint32_t *st
                     const bool got = (VOL && (ref & REF_VOL)) ? volume_leaf_t<VOL>(p, q0, q1, q2, r, inv, a, closest, rng, stk_ref, 0u, lane, t)
                                                      : sphere_t(mk(q0.x, q0.y, q0.z), q1.x, r, a, closest, t);
                     if (got) {
-                        closest = t; best_take(best, t, 0.0f, 0.0f, ref);
+                        closest = t; best_take(best, t, ref);
                     }
                 } else {
                     Best local;
@@ -1558,15 +1579,22 @@ constexpr uint32_t kWalkUnroll = 4u;
 
 // The head of world_hit<WORLD_BVH> for a lane that starts a segment: per-ray constants, the root's box.  Returns whether
 // the lane has a walk to take (the state is in cur / sp / best / inv / a).
+// (Measured and not adopted, round 3: the ROOT's node step done here, on the root's record carried in the launch parameters
+// and read by scalar loads -- every walk starts at the root, so it takes one trip out of the 13.3 lane-trips of a segment
+// on house.obj -- C1 / C3 / C4 70.23 / 83.80 / 70.07 ms against 70.26 / 83.98 / 70.05 without: the trip it saves is the
+// cheapest one, all lanes gathering one record, and its work moves into the latency-exposed shading round.)
 RTR_DEV bool begin_walk(const RenderParams &p, const Ray &ray, V3 &inv, float &a, Best &best, uint32_t &cur, uint32_t &sp) {
     a = dot(ray.d, ray.d);                                        // objects.rs:25, hoisted per ray
     inv = mk(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z);     // aabb.rs:86,103,120, hoisted per ray
     best_reset(best);
-    const uint32_t root = p.root_ref;
+    (void)p;
+    const KParams k = kernarg_params(); // (the root's ref and box: seven scalars loaded here instead of living across the walk)
+    const uint32_t root = k->root_ref;
     bool go = root != REF_NONE;
     if (go && (root & (REF_LEAF | REF_PAIR)) != REF_LEAF) {
         float e;
-        go = slab(p.root_box, p.root_box + 3, ray, inv, __builtin_inff(), e);
+        const float bmin[3] = {k->root_box[0], k->root_box[1], k->root_box[2]}, bmax[3] = {k->root_box[3], k->root_box[4], k->root_box[5]};
+        go = slab(bmin, bmax, ray, inv, __builtin_inff(), e);
     }
     cur = root; sp = 0u;
     return go;
@@ -1591,6 +1619,7 @@ __global__ __launch_bounds__(64, 6) void k_render_bvh(const RenderParams p) {
     cam.init(p);
     uint32_t nseg = 0;
     constexpr bool stack_packed = false;
+    WalkCounts counts;
 
     uint32_t ticket;
     if (claim_ticket(kernarg_params(), lane, ticket)) { // tickets, chunks and their hand-over: as in k_render
@@ -1663,7 +1692,9 @@ __global__ __launch_bounds__(64, 6) void k_render_bvh(const RenderParams p) {
 // Register budget: 7 waves per SIMD (72 VGPRs) for scenes without volumes -- with the lane states in scalar masks the
 // kernel needs 77, and the 7-wave build spills a few registers outside the walk (C1 +2.5 %, C3 +4 %); 6 waves for the
 // volume kernels, which would spill 8 ... 25.
-template <uint32_t VOL, bool MESH, bool PACKED>
+// COUNT: the instantiation behind option "traversal_counters" -- the same kernel, which also adds up its lanes' node steps,
+// leaf tests and SkyMap lookups (rtr_stats): a template flag, so that the counters cost the product kernel nothing.
+template <uint32_t VOL, bool MESH, bool PACKED, bool COUNT = false>
 __attribute__((amdgpu_num_sgpr(128)))
 __global__ __launch_bounds__(64, VOL == 0u ? 7 : 6) void k_render_bvh_sp(const RenderParams p) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
@@ -1716,6 +1747,7 @@ __global__ __launch_bounds__(64, VOL == 0u ? 7 : 6) void k_render_bvh_sp(const R
     // on every trip.
     uint64_t walking_m = 0ull;
     constexpr bool stack_packed = PACKED; // one-word stack entries (RenderParams::stack_packed, set for small trees)
+    WalkCounts counts;
     auto begin_segment = [&]() -> bool { nseg++; return begin_walk(p, ray, inv, a, best, cur, sp); }; // true = the lane has a walk to take
     uint64_t alive_m = 0ull;
     uint64_t need_m = wave_mask(true); // the lanes that want the workgroup's next (sample, pixel) pair
@@ -1794,6 +1826,7 @@ __global__ __launch_bounds__(64, VOL == 0u ? 7 : 6) void k_render_bvh_sp(const R
             V3 term;
             bool sky = false;
             const bool done = shade_segment(p, was_hit, h, ray, rng, lds_mats, chain, depth, term, &sky);
+            if (!was_hit && p.bg_kind == 2u) counts.sky++; // SkyMap::sample (evaluated here, or deferred to k_sum_samples)
             if (done) { // the sample's clamped radiance (render.rs:95-97) goes to memory; k_sum_samples adds them in order
                 // A path that escapes to a SkyMap leaves its DIRECTION and its attenuation chain instead (up to 3 material
                 // ids below 256, packed into the fourth word): k_sum_samples, whose lanes are all busy, does the
@@ -1832,6 +1865,14 @@ __global__ __launch_bounds__(64, VOL == 0u ? 7 : 6) void k_render_bvh_sp(const R
     if (lane < 32u && p.spp > 1u) atomicAdd(p.counter - 1 - lane, (unsigned long long)rtr_lsc[lane]);
 #endif
     count_segments(nseg, lane);
+    if constexpr (COUNT) {
+        unsigned long long t0 = counts.nodes, t1 = counts.leaves, t2 = counts.sky;
+        for (int off = 32; off > 0; off >>= 1) { t0 += __shfl_xor(t0, off, 64); t1 += __shfl_xor(t1, off, 64); t2 += __shfl_xor(t2, off, 64); }
+        if (lane == 0) {
+            unsigned long long *out = kernarg_params()->walk_counters;
+            atomicAdd(out, t0); atomicAdd(out + 1, t1); atomicAdd(out + 2, t2);
+        }
+    }
 }
 
 
@@ -1925,6 +1966,7 @@ __global__ __launch_bounds__(64, 6) void k_wf_intersect(const RenderParams p) {
     rng.state = 0u; rng.inc = 1u;
     bool walking = false; // the lane's walk is in progress
     bool holding = false; // the lane's walk has ended and its hit is not stored yet
+    WalkCounts counts;
     for (;;) {
         // ---- lanes without a path take the next waiting ones ----
         {
@@ -1963,7 +2005,7 @@ __global__ __launch_bounds__(64, 6) void k_wf_intersect(const RenderParams p) {
         const uint64_t held = __ballot(holding);
         if (held != 0ull && ((uint32_t)__popcll(held) >= p.wf_flush || __ballot(walking) == 0ull)) {
             if (holding) {
-                reinterpret_cast<float4 *>(p.wf_hit)[id] = make_float4(best.t, best.u, best.v, __uint_as_float(best.leaf));
+                reinterpret_cast<float4 *>(p.wf_hit)[id] = make_float4(best.t, 0.0f, 0.0f, __uint_as_float(best.leaf));
                 if constexpr (VOL) p.wf_state[4ull * id] = rng.state;
                 holding = false;
             }
@@ -2001,7 +2043,7 @@ __global__ __launch_bounds__(64) void k_wf_shade(const RenderParams p) {
             ray.o = mk(r0.x, r0.y, r0.z);
             ray.d = mk(r0.w, r1.x, r1.y);
             Best best;
-            best.t = hq.x; best.u = hq.y; best.v = hq.z; best.leaf = __float_as_uint(hq.w); best.cull = 0.0f;
+            best.t = hq.x; best.leaf = __float_as_uint(hq.w);
             Rng rng;
             rng.state = st.x; rng.inc = st.y;
             GlobalChain chain;
@@ -2216,6 +2258,15 @@ static const void *render_kernel(const RenderParams &p) {
         static const void *const packed[3][2] = {{RTR_FN(k_render_bvh_sp<0u, false, true>), RTR_FN(k_render_bvh_sp<0u, true, true>)},
                                                  {RTR_FN(k_render_bvh_sp<1u, false, true>), RTR_FN(k_render_bvh_sp<1u, true, true>)},
                                                  {RTR_FN(k_render_bvh_sp<2u, false, true>), RTR_FN(k_render_bvh_sp<2u, true, true>)}};
+        if (p.walk_counters) { // option "traversal_counters": the counting instantiations
+            static const void *const cw[3][2] = {{RTR_FN(k_render_bvh_sp<0u, false, false, true>), RTR_FN(k_render_bvh_sp<0u, true, false, true>)},
+                                                 {RTR_FN(k_render_bvh_sp<1u, false, false, true>), RTR_FN(k_render_bvh_sp<1u, true, false, true>)},
+                                                 {RTR_FN(k_render_bvh_sp<2u, false, false, true>), RTR_FN(k_render_bvh_sp<2u, true, false, true>)}};
+            static const void *const cp[3][2] = {{RTR_FN(k_render_bvh_sp<0u, false, true, true>), RTR_FN(k_render_bvh_sp<0u, true, true, true>)},
+                                                 {RTR_FN(k_render_bvh_sp<1u, false, true, true>), RTR_FN(k_render_bvh_sp<1u, true, true, true>)},
+                                                 {RTR_FN(k_render_bvh_sp<2u, false, true, true>), RTR_FN(k_render_bvh_sp<2u, true, true, true>)}};
+            return p.stack_packed ? cp[v][m] : cw[v][m];
+        }
         return p.stack_packed ? packed[v][m] : wide[v][m];
     }
     if (p.world == WORLD_BVH && p.resumable_walk) {

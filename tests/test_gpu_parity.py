@@ -894,3 +894,26 @@ def test_bilinear_sky_filter_matches_the_oracles_restatement(bvh):
         assert compare(mean, rgba, n_mean, n_rgba)["mismatched_pixels"] == 0
         with pytest.raises(rt.RtrError):
             r.set_option("sky_filter", "trilinear")
+
+
+@pytest.mark.parametrize("builder,w,h", [(lambda: house_scene(3), 160, 90), (lambda: simple_scene(4), 96, 96)])
+def test_traversal_counters_against_the_unculled_traversal(builder, w, h):
+    """Option "traversal_counters": the frame does not change; the device-counted node steps and leaf tests are positive and
+    bounded by the oracle's counts under the reference's unculled both-children traversal (bvh.rs:160-166: a node step
+    tests both children's boxes, so 2 * node_steps <= AABB::hit calls; the oracle also counts the root's own box)."""
+    scene = builder()
+    with rt.Renderer(0) as r:
+        r.upload_scene(scene)
+        ref, _ = r.render(w, h, seed=21)
+        plain = r.stats()
+        assert plain.traversal_counted == 0 and plain.node_steps == 0
+        r.set_option("traversal_counters", "on")
+        got, _ = r.render(w, h, seed=21)
+        st = r.stats()
+        assert np.array_equal(ref, got) and st.segments == plain.segments
+    _, _, o_st = pyoracle.OracleScene(scene).render(w, h, 21, threads=0)
+    assert st.traversal_counted == 1
+    assert 0 < 2 * st.node_steps <= o_st.box_tests
+    assert 0 < st.leaf_tests <= o_st.sphere_tests + o_st.tri_tests
+    assert st.node_steps >= st.segments * 0.5  # nearly every segment enters the root
+    assert st.sky_lookups == o_st.sky_lookups
