@@ -43,7 +43,15 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
 # "Wave scheduling" and the cycle-constants table).  Half-rate (compare / select / integer multiply) and quarter-rate
 # (sqrt / rcp) instructions and the clock the chip holds under load (< 2.4 GHz) keep 1.0 out of reach.
 VALU_PEAK_WAVE_INSTS_PER_S = 256 * 4 * 2.4e9 / 2.0
-PROFILE_ROUND = "r02"
+PROFILE_ROUND = "r03"
+# The tree kernels' bound (round 3): the vector L1's gather rate.  Every node step gathers a per-lane 56-byte record (three
+# 16-byte loads + one 8-byte load), every leaf test 36 (triangle) or 20 (sphere) bytes, and a wave's gather of per-lane
+# 64-byte-aligned records is served at 18-21 B per clock and CU whether the table sits in L1 or L2 -- measured with
+# scripts/ubench/gather.hip (profiles/r02/evidence/ubench_gather.txt: 56 B per lane, 16 KB table 12 795 GB/s, 1 MB table
+# 11 965 GB/s chip-wide).  Peak = the mean of the two; achieved = bytes the walk gathered (device-counted node steps and leaf
+# tests of one frame, option "traversal_counters") over the integrate kernel's time.
+L1_GATHER_PEAK_GBS = 12380.0
+NODE_GATHER_BYTES, TRIANGLE_GATHER_BYTES, SPHERE_GATHER_BYTES = 56.0, 36.0, 20.0
 
 
 def parse_args(argv=None):
@@ -200,8 +208,9 @@ def committed_profile(args, W, H, world):
     return d, "profiles/%s/%s.json" % (PROFILE_ROUND, workload_key(args, W, H))
 
 
-def roofline_block(prof, prof_status, integrate_ms, alg_bytes, kernel_name):
-    """Flat scalars only.  bound = VALU issue; the HBM side is what the counters measured, not a model."""
+def roofline_block(prof, prof_status, integrate_ms, alg_bytes, kernel_name, walk=None):
+    """Flat scalars only.  Sphere world: bound = VALU issue; tree worlds (walk given): bound = the vector L1's gather rate,
+    the VALU figures beside it.  The HBM side is what the counters measured, not a model."""
     out = {"bound": "valu_issue", "achieved": None, "peak": round(VALU_PEAK_WAVE_INSTS_PER_S / 1e9, 1),
            "unit": "G wave-instructions/s", "frac": None, "traffic": None,
            "active_lane_fraction": None, "lane_throughput_frac": None,
@@ -212,15 +221,28 @@ def roofline_block(prof, prof_status, integrate_ms, alg_bytes, kernel_name):
            "aux_streaming_model_note": "SURVEY 8(d)'s algorithmic bytes (48 B of path state in and out per segment + "
                                        "geometry records) over the kernel time: a model of a streaming design, bytes "
                                        "this register-resident kernel never moves; not a bound"}
+    if walk is not None and integrate_ms > 0:
+        # tree world: what binds is the vector L1 (see L1_GATHER_PEAK_GBS); the VALU-issue figures move to valu_* keys
+        gbs = walk["gather_bytes"] / (integrate_ms * 1e-3) / 1e9
+        out.update({"bound": "vector_l1_gather", "achieved": round(gbs, 1), "peak": L1_GATHER_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(gbs / L1_GATHER_PEAK_GBS, 4),
+                    "gather_bytes_per_launch": walk["gather_bytes"], "node_steps_per_segment": walk["node_steps_per_segment"],
+                    "leaf_tests_per_segment": walk["leaf_tests_per_segment"],
+                    "peak_source": "scripts/ubench/gather.hip on this GPU type: per-lane 56-byte record gathers, L1- and L2-resident "
+                                   "tables (profiles/r02/evidence/ubench_gather.txt)"})
     if prof is None or integrate_ms <= 0:
         return out
     t = integrate_ms * 1e-3
     ach = float(prof["sq_insts_valu"]) / t
-    out["achieved"] = round(ach / 1e9, 1)
-    out["frac"] = round(ach / VALU_PEAK_WAVE_INSTS_PER_S, 4)
+    if walk is not None:
+        out["valu_achieved_g_wave_insts_per_s"] = round(ach / 1e9, 1)
+        out["valu_issue_frac"] = round(ach / VALU_PEAK_WAVE_INSTS_PER_S, 4)
+    else:
+        out["achieved"] = round(ach / 1e9, 1)
+        out["frac"] = round(ach / VALU_PEAK_WAVE_INSTS_PER_S, 4)
     if prof.get("active_lane_fraction") is not None:
         out["active_lane_fraction"] = round(float(prof["active_lane_fraction"]), 4)
-        out["lane_throughput_frac"] = round(out["frac"] * out["active_lane_fraction"], 4)
+        out["lane_throughput_frac"] = round(ach / VALU_PEAK_WAVE_INSTS_PER_S * out["active_lane_fraction"], 4)
     if prof.get("hbm_bytes_per_launch") is not None:
         out["traffic"] = float(prof["hbm_bytes_per_launch"])
         out["hbm_achieved_gbs"] = round(out["traffic"] / t / 1e9, 2)
@@ -255,6 +277,8 @@ def cpu_baseline(scene, width, height, spp_sample, seed):
     sc.settings.samples_per_pixel = spp_sample
     rgba, _, st = pyoracle.OracleScene(sc, trig_mode=pyoracle.TRIG_POLY).render(width, height, seed, threads=cores, want_rgba8=True, want_mean=False)
     rec = {
+        "unculled_box_tests_per_segment": round(st.box_tests / max(st.segments, 1), 2),
+        "unculled_leaf_tests_per_segment": round((st.sphere_tests + st.tri_tests) / max(st.segments, 1), 2),
         "value": round(st.segments / st.seconds / 1e6, 3), "unit": "Mrays/s", "cores": int(st.threads), "kind": "port",
         "sample": f"full {width}x{height} frame at {spp_sample} spp (of {scene.settings.samples_per_pixel}), "
                   f"{st.segments} segments in {st.seconds:.2f} s; C restatement of the reference "
@@ -461,6 +485,20 @@ def main():
             BYTES_PER_SEGMENT["c2b"] if args.bvh else BYTES_PER_SEGMENT["c2"])
         alg_bytes = b_seg * seg_per_launch + 4.0 * pixels_per_launch
         prof, prof_status = committed_profile(args, W, H, args.gpus if args.native else world)
+        walk = None
+        if scene.settings.enable_bvh_tree and world == 1 and not args.native and not args.tree_kernel:
+            # one more frame of the last timed seed through the counting instantiation of the samples kernel: what the walk gathered
+            r.set_option("traversal_counters", "on")
+            r.render_frame_device(W, H, args.seed + args.warmup + args.steps - 1, rgba8.data_ptr(), stream)
+            cst = r.stats()
+            r.set_option("traversal_counters", "off")
+            if cst.traversal_counted:
+                info = r.scene_info()
+                tri_share = info.n_triangles / max(info.n_leaves, 1)
+                leaf_bytes = tri_share * TRIANGLE_GATHER_BYTES + (1.0 - tri_share) * SPHERE_GATHER_BYTES
+                walk = {"gather_bytes": float(cst.node_steps) * NODE_GATHER_BYTES + float(cst.leaf_tests) * leaf_bytes,
+                        "node_steps_per_segment": round(cst.node_steps / max(cst.segments, 1), 2),
+                        "leaf_tests_per_segment": round(cst.leaf_tests / max(cst.segments, 1), 2)}
         out = {
             "metric": "Mrays/s", "value": round(mrays, 2), "unit": "Mrays/s", "n_gpus": args.gpus if args.native else world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
@@ -481,7 +519,7 @@ def main():
                 "upload_ms": round(float(stats.upload_ms), 3),
                 "parity": "unpinned (the reference holds no fixtures and cannot be built here); checked against oracle/",
             },
-            "roofline": roofline_block(prof, prof_status, my_integrate_ms, alg_bytes, r.kernel_name()),
+            "roofline": roofline_block(prof, prof_status, my_integrate_ms, alg_bytes, r.kernel_name(), walk),
         }
         if not args.no_cpu_baseline and world == 1 and not (args.native and args.gpus > 1):
             rec, o_rgba, o_spp, o_segments = cpu_baseline(scene, W, H, args.cpu_spp, args.seed)

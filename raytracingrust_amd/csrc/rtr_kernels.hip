@@ -1689,14 +1689,14 @@ __global__ __launch_bounds__(64, 6) void k_render_bvh(const RenderParams p) {
 // as they finish (ballot + mbcnt hand-out); each sample's clamped radiance is written to p.samples[sample][pixel], and
 // k_sum_samples adds a pixel's samples in index order afterwards (the same additions as calculate_pixel's loop).  No lane
 // waits for its tile's slowest pixel, no wave for a slower one, and nothing is handed over between workgroups.
-// Register budget: 7 waves per SIMD (72 VGPRs) for scenes without volumes -- with the lane states in scalar masks the
-// kernel needs 77, and the 7-wave build spills a few registers outside the walk (C1 +2.5 %, C3 +4 %); 6 waves for the
-// volume kernels, which would spill 8 ... 25.
+// Register budget (round 3: two-register best hit, per-block parameters read through the kernarg pointer -- the 7-wave
+// build no longer spills a vector register): mesh scenes 8 waves per SIMD (64 VGPRs, 9 spilled outside the walk: C3 / C4
+// +1.6 / +1.5 % over 7), sphere scenes 7 (72 VGPRs; 8 waves: -0.9 %), the volume kernels 6.
 // COUNT: the instantiation behind option "traversal_counters" -- the same kernel, which also adds up its lanes' node steps,
 // leaf tests and SkyMap lookups (rtr_stats): a template flag, so that the counters cost the product kernel nothing.
 template <uint32_t VOL, bool MESH, bool PACKED, bool COUNT = false>
 __attribute__((amdgpu_num_sgpr(128)))
-__global__ __launch_bounds__(64, VOL == 0u ? 7 : 6) void k_render_bvh_sp(const RenderParams p) {
+__global__ __launch_bounds__(64, VOL == 0u ? (MESH ? 8 : 7) : 6) void k_render_bvh_sp(const RenderParams p) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const uint32_t lane = threadIdx.x;
 #ifdef RTR_X_LANESTAT

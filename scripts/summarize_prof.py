@@ -47,6 +47,7 @@ for f in find("trace/**/*kernel_trace.csv"):
 dominant = max((n for n in durations if is_integrate(n)), key=lambda n: sum(durations[n]), default=None)
 print("== PMC (per dispatch of each integrate kernel: mean over dispatches) ==")
 pmc = defaultdict(dict)
+totals = defaultdict(dict)
 for d in ("pmc_sq1", "pmc_sq2", "pmc_fetch", "pmc_write"):
     acc = defaultdict(list)
     for f in find(d + "/**/*counter_collection.csv"):
@@ -61,6 +62,7 @@ for d in ("pmc_sq1", "pmc_sq2", "pmc_fetch", "pmc_write"):
                 acc[(name, counter)].append(v)
     for (name, counter), vals in sorted(acc.items()):
         pmc[name][counter] = sum(vals) / len(vals)
+        totals[name][counter] = sum(vals)  # over every dispatch of the run: what a per-STEP figure is made from
         print(f"{d:10s} {name[:48]:48s} {counter:26s} n={len(vals)} mean={sum(vals) / len(vals):.6g}")
 
 if dominant:
@@ -76,8 +78,11 @@ if dominant:
         W, H = args.width, args.height
     c = pmc.get(dominant, {})
     # every kernel of one bench step: HBM traffic is reported for the whole step (integrate + sum), VALU for the dominant one
-    fetch = sum(v.get("FETCH_SIZE", 0.0) for v in pmc.values())
-    write = sum(v.get("WRITE_SIZE", 0.0) for v in pmc.values())
+    # (each kernel has its own number of dispatches per step -- the integrate kernel one per batch, k_sum_samples one per batch,
+    # the streaming kernels one per depth: sum over every dispatch of the run, divided by the steps that were run)
+    steps_run = max(args.steps + args.warmup, 1)
+    fetch = sum(v.get("FETCH_SIZE", 0.0) for v in totals.values()) / steps_run
+    write = sum(v.get("WRITE_SIZE", 0.0) for v in totals.values()) / steps_run
     calls_ratio = 1.0
     rec = {
         "_comment": "scripts/profile_bench.sh: rocprofv3 --kernel-trace --stats, then separate --pmc passes, of `python3 bench.py "
