@@ -575,6 +575,12 @@ class Renderer {
     explicit Renderer(int device = 0) {
         if (rtr_create(device, &ctx_) != RTR_OK) throw std::runtime_error(std::string("rtr_create: ") + rtr_last_error(nullptr));
     }
+    // one context over several GPUs of this node (rtr_create_multi): every frame is divided among them inside the library
+    // -- what render()'s rayon fan-out (lib/core/render.rs:114-119) becomes on a node of GPUs
+    explicit Renderer(const std::vector<int> &devices) {
+        if (rtr_create_multi(devices.data(), (int)devices.size(), &ctx_) != RTR_OK)
+            throw std::runtime_error(std::string("rtr_create_multi: ") + rtr_last_error(nullptr));
+    }
     ~Renderer() { rtr_destroy(ctx_); }
     Renderer(const Renderer &) = delete;
     Renderer &operator=(const Renderer &) = delete;
@@ -623,6 +629,13 @@ class Renderer {
 inline void render(RenderTarget &target, const Scene &scene, uint64_t seed, int device = 0) {
     target.request_redraw = true;
     Renderer r(device);
+    r.upload(scene);
+    r.render(scene, target, seed);
+}
+// ... over several GPUs
+inline void render(RenderTarget &target, const Scene &scene, uint64_t seed, const std::vector<int> &devices) {
+    target.request_redraw = true;
+    Renderer r(devices);
     r.upload(scene);
     r.render(scene, target, seed);
 }

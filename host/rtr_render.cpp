@@ -5,6 +5,7 @@
 //   rtr_render --scene ... --host-only --info                            (no GPU: lowering + BVH statistics only)
 //
 // Options: --bvh 0|1, --depth N, --mode Full|Clay|Random|Normal, --f32 file (raw mean radiance floats), --device N,
+//          --devices 0,1,2,3 (one context over several GPUs: rtr_create_multi divides every frame among them),
 //          --fast-trees (rebuild mesh and scene trees with the surface-area heuristic: same hits, faster walk),
 //          --device-trees (build the mesh trees on the GPU as linear BVHs: same hits, fast build, slower walk),
 //          --sky file.pfm (replace the scene's background by a SkyMap read from a colour Portable Float Map).
@@ -45,6 +46,7 @@ int main(int argc, char **argv) {
     long spp = -1, depth = -1, bvh = -1;
     uint64_t seed = 0x5EED;
     int device = 0;
+    std::vector<int> devices;
     bool info = false, host_only = false, fast_trees = false, device_trees = false;
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
@@ -62,6 +64,15 @@ int main(int argc, char **argv) {
         else if (a == "--mode") mode = next();
         else if (a == "--seed") seed = std::strtoull(next(), nullptr, 0);
         else if (a == "--device") device = (int)std::strtol(next(), nullptr, 0);
+        else if (a == "--devices") { // comma-separated GPU indices
+            const std::string list = next();
+            for (size_t i = 0; i < list.size();) {
+                size_t j = list.find(',', i);
+                if (j == std::string::npos) j = list.size();
+                devices.push_back((int)std::strtol(list.substr(i, j - i).c_str(), nullptr, 0));
+                i = j + 1;
+            }
+        }
         else if (a == "--info") info = true;
         else if (a == "--host-only") host_only = true;
         else if (a == "--fast-trees") fast_trees = true;
@@ -80,7 +91,8 @@ int main(int argc, char **argv) {
         if (!mode.empty())
             scene.settings.mode = mode == "Clay" ? rtr::RenderMode::Clay : mode == "Random" ? rtr::RenderMode::Random
                                 : mode == "Normal" ? rtr::RenderMode::Normal : rtr::RenderMode::Full;
-        rtr::Renderer r(host_only ? -1 : device);
+        if (host_only) devices.assign(devices.size(), -1);
+        rtr::Renderer r = devices.empty() ? rtr::Renderer(host_only ? -1 : device) : rtr::Renderer(devices);
         if (fast_trees) { r.set_option("mesh_tree", "sah"); r.set_option("scene_tree", "sah"); }
         if (device_trees) r.set_option("mesh_tree", "lbvh"); // mesh trees built on the GPU (csrc/rtr_lbvh.hip)
         r.upload(scene);
