@@ -69,6 +69,7 @@ struct Lowered {
     std::vector<rtr_material> materials;
     std::vector<rtr_volume> volumes;
     std::vector<rtr_mesh> boundary_meshes; // meshes that only bound a Volume: appended behind the objects' meshes by Scene::lower
+    std::vector<rtr_volume> boundary_volumes; // Volumes that only bound a Volume: appended behind the objects' Volumes likewise
     rtr_background background{};
     rtr_scene_desc desc() const {
         rtr_scene_desc d{};
@@ -251,17 +252,31 @@ class Mesh : public Object { // mesh.rs:31-121
     std::string to_json() const override { throw std::runtime_error("Mesh cannot be serialized (the reference panics: mesh.rs:40-49)"); }
 };
 
-class Volume : public Object { // volume.rs:19-32: `boundary: Box<dyn Object>` -- a Sphere or a Mesh here
+class Volume : public Object { // volume.rs:19-32: `boundary: Box<dyn Object>` -- a Sphere, a Mesh or another Volume
   public:
     Volume(Sphere boundary, float density) : sphere(std::move(boundary)), neg_inv_density(-1.0f / density) {}
     Volume(std::unique_ptr<Mesh> boundary, float density) : sphere(Vec3{0, 0, 0}, 0.0f, boundary->mat), mesh(std::move(boundary)), neg_inv_density(-1.0f / density) {}
-    Sphere sphere;              // the boundary when mesh is null
-    std::unique_ptr<Mesh> mesh; // the boundary otherwise
+    Volume(std::unique_ptr<Volume> boundary, float density) : sphere(Vec3{0, 0, 0}, 0.0f, boundary->material()), inner(std::move(boundary)), neg_inv_density(-1.0f / density) {}
+    Sphere sphere;                 // the boundary when mesh and inner are null
+    std::unique_ptr<Mesh> mesh;    // the boundary ...
+    std::unique_ptr<Volume> inner; // ... or this one (the GPU path lowers one level of Volume-in-Volume)
     float neg_inv_density;
-    MaterialHandle material() const override { return mesh ? mesh->material() : sphere.material(); } // volume.rs:98-100
+    MaterialHandle material() const override { return inner ? inner->material() : mesh ? mesh->material() : sphere.material(); } // volume.rs:98-100
     void lower(Lowered &out) const override {
+        rtr_volume v = record(out);
+        out.objects.push_back(rtr_object{RTR_OBJ_VOLUME, (uint32_t)out.volumes.size()});
+        out.volumes.push_back(v);
+    }
+    // this Volume's rtr_volume; a boundary mesh / Volume goes to out.boundary_meshes / out.boundary_volumes (rebased by Scene::lower)
+    rtr_volume record(Lowered &out) const {
         rtr_volume v{};
-        if (mesh) {
+        if (inner) {
+            const rtr_volume b = inner->record(out);
+            v.boundary.material = (uint32_t)material().index;
+            v.boundary_kind = RTR_OBJ_VOLUME;
+            v.boundary_mesh = (uint32_t)out.boundary_volumes.size();
+            out.boundary_volumes.push_back(b);
+        } else if (mesh) {
             rtr_mesh m{};
             m.positions = mesh->positions.data(); m.normals = mesh->normals.data(); m.indices = mesh->indices.data();
             m.n_verts = (uint32_t)(mesh->positions.size() / 3); m.n_tris = (uint32_t)(mesh->indices.size() / 3); m.material = (uint32_t)mesh->mat.index;
@@ -274,12 +289,11 @@ class Volume : public Object { // volume.rs:19-32: `boundary: Box<dyn Object>` -
             v.boundary.radius = sphere.radius; v.boundary.material = (uint32_t)sphere.mat.index;
         }
         v.neg_inv_density = neg_inv_density;
-        out.objects.push_back(rtr_object{RTR_OBJ_VOLUME, (uint32_t)out.volumes.size()});
-        out.volumes.push_back(v);
+        return v;
     }
     std::string to_json() const override {
         if (mesh) throw std::runtime_error("a Volume over a Mesh cannot be serialized (Mesh panics in the reference: mesh.rs:40-49)");
-        return "{\"type\": \"Volume\", \"boundary\": " + sphere.to_json() + ", \"neg_inv_density\": " + jsonw::num(neg_inv_density) + "}";
+        return "{\"type\": \"Volume\", \"boundary\": " + (inner ? inner->to_json() : sphere.to_json()) + ", \"neg_inv_density\": " + jsonw::num(neg_inv_density) + "}";
     }
 };
 
@@ -458,13 +472,8 @@ class Scene {
             const std::string &ot = o.at("type").s;
             if (ot == "Sphere") s.add_object(std::make_unique<Sphere>(xyz(o.at("center")), o.at("radius").f(), MaterialHandle{(size_t)o.at("material").n}));
             else if (ot == "Mesh") throw std::runtime_error("Mesh cannot be deserialized (the reference panics: mesh.rs:51-60)");
-            else if (ot == "Volume") {
-                const json::Value &b = o.at("boundary");
-                if (b.at("type").s != "Sphere") throw std::runtime_error("Volume boundaries other than Sphere are outside the GPU path");
-                auto v = std::make_unique<Volume>(Sphere(xyz(b.at("center")), b.at("radius").f(), MaterialHandle{(size_t)b.at("material").n}), 1.0f);
-                v->neg_inv_density = o.at("neg_inv_density").f();
-                s.add_object(std::move(v));
-            } else throw std::runtime_error("unknown object type " + ot);
+            else if (ot == "Volume") s.add_object(volume_from(o));
+            else throw std::runtime_error("unknown object type " + ot);
         }
         return s;
     }
@@ -477,8 +486,14 @@ class Scene {
         for (auto &o : objects) o->lower(out);
         // meshes that bound a Volume follow the objects' meshes (the order raytracingrust_amd/scene.py uses too)
         const uint32_t n_object_meshes = (uint32_t)out.meshes.size();
-        for (auto &v : out.volumes)
+        // ... and Volumes that bound a Volume follow the objects' Volumes
+        const uint32_t n_object_volumes = (uint32_t)out.volumes.size();
+        out.volumes.insert(out.volumes.end(), out.boundary_volumes.begin(), out.boundary_volumes.end());
+        out.boundary_volumes.clear();
+        for (auto &v : out.volumes) {
             if (v.boundary_kind == RTR_OBJ_MESH) v.boundary_mesh += n_object_meshes;
+            if (v.boundary_kind == RTR_OBJ_VOLUME) v.boundary_mesh += n_object_volumes;
+        }
         out.meshes.insert(out.meshes.end(), out.boundary_meshes.begin(), out.boundary_meshes.end());
         out.boundary_meshes.clear();
         background->lower(out.background);
@@ -488,6 +503,16 @@ class Scene {
     std::vector<std::unique_ptr<Material>> materials_; // private in the reference too (scene.rs:39)
     static Vec3 xyz(const json::Value &v) { return Vec3{v.at("x").f(), v.at("y").f(), v.at("z").f()}; }
     static Color rgb(const json::Value &v) { return Color{v.at("r").f(), v.at("g").f(), v.at("b").f()}; }
+    static std::unique_ptr<Volume> volume_from(const json::Value &o) { // {"type": "Volume", "boundary": Sphere | Volume, "neg_inv_density"}
+        const json::Value &b = o.at("boundary");
+        std::unique_ptr<Volume> v;
+        if (b.at("type").s == "Sphere")
+            v = std::make_unique<Volume>(Sphere(xyz(b.at("center")), b.at("radius").f(), MaterialHandle{(size_t)b.at("material").n}), 1.0f);
+        else if (b.at("type").s == "Volume") v = std::make_unique<Volume>(volume_from(b), 1.0f);
+        else throw std::runtime_error("a Volume over a Mesh cannot be deserialized (Mesh panics in the reference: mesh.rs:51-60)");
+        v->neg_inv_density = o.at("neg_inv_density").f();
+        return v;
+    }
     static std::unique_ptr<Material> material_from(const json::Value &m) {
         const std::string &t = m.at("type").s;
         if (t == "Lambertian") return std::make_unique<Lambertian>(rgb(m.at("albedo")));

@@ -57,7 +57,7 @@ typedef enum rtr_status {
     RTR_ERR_NAN_CENTROID = -5,     /* partial_cmp().unwrap() in the BVH builder would panic (bvh.rs:99,109,119) */
     RTR_ERR_BAD_SETTINGS = -6,     /* clamp_indirect NaN/negative (f32::clamp panics, render.rs:95), empty target */
     RTR_ERR_NO_SCENE = -7,         /* render before rtr_upload_scene */
-    RTR_ERR_UNSUPPORTED = -8,      /* scene feature outside the GPU path (Volume with a mesh boundary, LDS budget) */
+    RTR_ERR_UNSUPPORTED = -8,      /* scene feature outside the GPU path (Volumes nested more than one level deep, LDS budget) */
     RTR_ERR_OUT_OF_MEMORY = -9
 } rtr_status;
 
@@ -99,13 +99,16 @@ typedef struct rtr_mesh {
  * boundary_kind = RTR_OBJ_SPHERE: `boundary` is the sphere.  boundary_kind = RTR_OBJ_MESH (ABI revision 4):
  * meshes[boundary_mesh] is the boundary; Volume::hit then makes its two boundary.hit calls (volume.rs:35-36) through
  * that mesh's own tree with the ranges [-inf, +inf] and [t1 + tmin, +inf] -- Triangle::hit takes the lower bound as its
- * determinant epsilon too (mesh.rs:166,190), which is reproduced.  The boundary's material is the medium's (normally
- * Isotropic).  A boundary sphere or mesh is NOT listed in objects[] itself. */
+ * determinant epsilon too (mesh.rs:166,190), which is reproduced.  boundary_kind = RTR_OBJ_VOLUME (ABI revision 5):
+ * volumes[boundary_mesh] -- the same index field -- is the boundary, itself a Volume over a sphere or a mesh (one level of
+ * nesting; deeper chains are RTR_ERR_UNSUPPORTED): the two boundary.hit calls are then Volume::hit again, each with its
+ * own random draw, in call order.  The boundary's material is the medium's (normally Isotropic).  A boundary sphere, mesh
+ * or Volume is NOT listed in objects[] itself. */
 typedef struct rtr_volume {
     rtr_sphere boundary;
     float neg_inv_density; /* -1/density, as Volume::new stores it (volume.rs:29) */
-    uint32_t boundary_kind; /* RTR_OBJ_SPHERE (0) | RTR_OBJ_MESH (1) */
-    uint32_t boundary_mesh; /* index into meshes[] when boundary_kind = RTR_OBJ_MESH */
+    uint32_t boundary_kind; /* RTR_OBJ_SPHERE (0) | RTR_OBJ_MESH (1) | RTR_OBJ_VOLUME (2) */
+    uint32_t boundary_mesh; /* index into meshes[] (boundary_kind = RTR_OBJ_MESH) or into volumes[] (RTR_OBJ_VOLUME) */
 } rtr_volume;
 
 typedef struct rtr_material {

@@ -53,6 +53,7 @@ def lib():
         L.or_add_mesh.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_int]
         L.or_add_volume_sphere.argtypes = [C.c_void_p, _f3, C.c_float, C.c_int, C.c_float]
         L.or_add_volume_mesh.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_int, C.c_float]
+        L.or_wrap_last_volume.argtypes = [C.c_void_p, C.c_float]
         L.or_render.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64, C.c_int, C.c_uint32, C.c_uint32,
                                 C.c_void_p, C.c_void_p, C.POINTER(or_stats)]
         L.or_camera_ray_origin.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
@@ -125,6 +126,10 @@ class OracleScene:
                                           o.indices.ctypes.data_as(C.c_void_p), o.n_tris,
                                           remap.get(o.material, o.material)))
             elif isinstance(o, S.Volume):
+                chain = [o]  # outermost first; Volume::new(Box::new(inner), density) from the inside out
+                while isinstance(chain[-1].boundary, S.Volume):
+                    chain.append(chain[-1].boundary)
+                o = chain[-1]
                 b = o.boundary
                 if isinstance(b, S.Mesh):
                     self._check(L.or_add_volume_mesh(self._s, b.positions.ctypes.data_as(C.c_void_p),
@@ -134,6 +139,8 @@ class OracleScene:
                 else:
                     self._check(L.or_add_volume_sphere(self._s, f3(b.center), float(np.float32(b.radius)),
                                                        remap.get(b.material, b.material), float(np.float32(o.density))))
+                for outer in reversed(chain[:-1]):
+                    self._check(L.or_wrap_last_volume(self._s, float(np.float32(outer.density))))
             else:
                 raise TypeError(o)
 

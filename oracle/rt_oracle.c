@@ -206,9 +206,12 @@ typedef struct {                                                    /* mesh.rs:3
     bvh_node *bvh_root;
     int material;
 } mesh_t;
-/* volume.rs:19-23: `boundary: Box<dyn Object>` -- a sphere, or a mesh (boundary_mesh != NULL; the mesh's material is the
- * medium's, Object::material of Mesh) */
-typedef struct { sphere_t boundary; mesh_t *boundary_mesh; float neg_inv_density; } volume_t;
+/* volume.rs:19-23: `boundary: Box<dyn Object>` -- a sphere, a mesh (boundary_mesh != NULL; the mesh's material is the
+ * medium's, Object::material of Mesh) or another Volume (boundary_volume != NULL, to any depth) */
+typedef struct volume_s { sphere_t boundary; mesh_t *boundary_mesh; struct volume_s *boundary_volume; float neg_inv_density; } volume_t;
+static int volume_material(const volume_t *v) { /* Object::material = boundary.material(), volume.rs:98-100 */
+    return v->boundary_volume ? volume_material(v->boundary_volume) : (v->boundary_mesh ? v->boundary_mesh->material : v->boundary.material);
+}
 
 enum { OBJ_SPHERE = 0, OBJ_MESH = 1, OBJ_VOLUME = 2 };
 typedef struct { int kind; sphere_t sphere; mesh_t *mesh; volume_t volume; } object_t;
@@ -321,7 +324,11 @@ static aabb_t coll_bounds(const collection *c, uint32_t handle) {
     switch (o->kind) {
     case OBJ_SPHERE: return sphere_bounds(&o->sphere);
     case OBJ_MESH: return o->mesh->bounds;                        /* mesh.rs:234-238 */
-    default: return o->volume.boundary_mesh ? o->volume.boundary_mesh->bounds : sphere_bounds(&o->volume.boundary); /* volume.rs:90-94 */
+    default: { /* Bounded for Volume = boundary.bounds(), volume.rs:90-94 */
+        const volume_t *v = &o->volume;
+        while (v->boundary_volume) v = v->boundary_volume;
+        return v->boundary_mesh ? v->boundary_mesh->bounds : sphere_bounds(&v->boundary);
+    }
     }
 }
 static int coll_hit(const collection *c, uint32_t handle, const ray_t *ray, float tmin, float tmax, hit_t *out,
@@ -414,7 +421,9 @@ static int bvh_hit(const bvh_node *n, const ray_t *ray, float tmin, float tmax, 
 
 static inline float or_log(float x, int mode);
 /* self.boundary.hit(ray, tmin, tmax) for the two kinds of boundary a Volume is built over here (volume.rs:35-36) */
-static int volume_boundary_hit(const volume_t *v, const ray_t *ray, float tmin, float tmax, hit_t *out, tctx_t *tc) {
+static int volume_hit(const volume_t *v, const ray_t *ray, float tmin, float tmax, hit_t *out, tctx_t *tc, int trig_mode);
+static int volume_boundary_hit(const volume_t *v, const ray_t *ray, float tmin, float tmax, hit_t *out, tctx_t *tc, int trig_mode) {
+    if (v->boundary_volume) return volume_hit(v->boundary_volume, ray, tmin, tmax, out, tc, trig_mode); /* Hittable for Volume again */
     if (v->boundary_mesh) { /* Mesh::hit, mesh.rs:124-127: the mesh's own tree with the caller's range; Triangle::hit
                              * takes tmin as its determinant epsilon and its lower bound on t, and ignores tmax */
         collection c = {NULL, v->boundary_mesh};
@@ -425,8 +434,8 @@ static int volume_boundary_hit(const volume_t *v, const ray_t *ray, float tmin, 
 /* lib/volume.rs:34-73  Volume::hit */
 static int volume_hit(const volume_t *v, const ray_t *ray, float tmin, float tmax, hit_t *out, tctx_t *tc, int trig_mode) {
     hit_t hit1, hit2;
-    if (!volume_boundary_hit(v, ray, -INFINITY, INFINITY, &hit1, tc)) return 0;
-    if (!volume_boundary_hit(v, ray, hit1.t + tmin, INFINITY, &hit2, tc)) return 0;
+    if (!volume_boundary_hit(v, ray, -INFINITY, INFINITY, &hit1, tc, trig_mode)) return 0;
+    if (!volume_boundary_hit(v, ray, hit1.t + tmin, INFINITY, &hit2, tc, trig_mode)) return 0;
     if (hit1.t < tmin) hit1.t = tmin;
     if (hit2.t > tmax) hit2.t = tmax;
     if (hit1.t >= hit2.t) return 0;
@@ -437,7 +446,7 @@ static int volume_hit(const volume_t *v, const ray_t *ray, float tmin, float tma
     float hit_distance = v->neg_inv_density * or_log(random_float, trig_mode);
     if (hit_distance > distance_inside_boundary) return 0;
     float t = hit1.t + hit_distance / ray_length;
-    *out = hit_new(ray_at(ray, t), v3_new(1.0f, 0.0f, 0.0f), t, ray, v->boundary_mesh ? v->boundary_mesh->material : v->boundary.material);
+    *out = hit_new(ray_at(ray, t), v3_new(1.0f, 0.0f, 0.0f), t, ray, volume_material(v));
     return 1;
 }
 
@@ -816,7 +825,7 @@ static bvh_node *scene_build_bvh(const or_scene *s, int *err) { /* scene.rs:112-
 static int validate(const or_scene *s) {
     for (int i = 0; i < s->n_objects; i++) {
         const object_t *o = &s->objects[i];
-        int m = o->kind == OBJ_SPHERE ? o->sphere.material : (o->kind == OBJ_MESH ? o->mesh->material : (o->volume.boundary_mesh ? o->volume.boundary_mesh->material : o->volume.boundary.material));
+        int m = o->kind == OBJ_SPHERE ? o->sphere.material : (o->kind == OBJ_MESH ? o->mesh->material : volume_material(&o->volume));
         if (m < 0 || m >= s->n_materials) return or_fail(-3, "material index out of bounds (scene.rs:106-110 would panic)");
     }
     if (!(s->clamp_indirect == s->clamp_indirect) || s->clamp_indirect < 0.0f)
@@ -896,7 +905,16 @@ void or_scene_free(or_scene *s) {
     if (!s) return;
     for (int i = 0; i < s->n_objects; i++) {
         if (s->objects[i].kind == OBJ_MESH) mesh_free(s->objects[i].mesh);
-        if (s->objects[i].kind == OBJ_VOLUME && s->objects[i].volume.boundary_mesh) mesh_free(s->objects[i].volume.boundary_mesh);
+        if (s->objects[i].kind == OBJ_VOLUME) {
+            volume_t *v = &s->objects[i].volume, *inner = v->boundary_volume;
+            if (v->boundary_mesh) mesh_free(v->boundary_mesh);
+            while (inner) { /* the chain of boxed boundary Volumes */
+                volume_t *next = inner->boundary_volume;
+                if (inner->boundary_mesh) mesh_free(inner->boundary_mesh);
+                free(inner);
+                inner = next;
+            }
+        }
     }
     free(s->objects); free(s->materials); free(s->sky); free(s);
 }
@@ -1009,6 +1027,18 @@ int or_add_volume_mesh(or_scene *s, const float *positions, const float *normals
     object_t *o = push_object(s);
     o->kind = OBJ_VOLUME;
     o->volume.boundary_mesh = m;
+    o->volume.neg_inv_density = -1.0f / density;
+    return s->n_objects - 1;
+}
+/* Volume::new(Box::new(<the Volume added last>), density): the scene's last object, which must be a Volume, becomes the
+ * boundary of a new Volume that takes its place (volume.rs:20 admits any Object as a boundary) */
+int or_wrap_last_volume(or_scene *s, float density) {
+    if (s->n_objects < 1 || s->objects[s->n_objects - 1].kind != OBJ_VOLUME) return or_fail(-9, "the last object is not a Volume");
+    object_t *o = &s->objects[s->n_objects - 1];
+    volume_t *inner = (volume_t *)malloc(sizeof *inner);
+    *inner = o->volume;
+    memset(&o->volume, 0, sizeof o->volume);
+    o->volume.boundary_volume = inner;
     o->volume.neg_inv_density = -1.0f / density;
     return s->n_objects - 1;
 }

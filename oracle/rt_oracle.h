@@ -89,6 +89,8 @@ int or_add_volume_sphere(or_scene *s, const float center[3], float radius, int m
 /* Volume over a mesh boundary (volume.rs:20 `boundary: Box<dyn Object>`): the mesh is built as or_add_mesh builds it */
 int or_add_volume_mesh(or_scene *s, const float *positions, const float *normals, uint32_t n_verts, const uint32_t *indices,
                        uint32_t n_tris, int material, float density);
+/* wraps the object added last (a Volume) into a new Volume of the given density: Volume::new(Box::new(volume), density) */
+int or_wrap_last_volume(or_scene *s, float density);
 
 /* render(), render.rs:61-127.  rgba8: W*H*4 bytes (may be NULL).  mean_rgb: W*H*3 floats holding
  * color/spp BEFORE the sqrt gamma (render.rs:103-107), may be NULL.  threads<=0: all cores when

@@ -45,7 +45,6 @@ hipError_t launch_wf_shade(const RenderParams &p, uint32_t grid, hipStream_t str
 uint32_t wf_resident_waves(const RenderParams &p, bool shade);
 uint32_t wf_intersect_lds_bytes(const RenderParams &p);
 uint32_t stack_entry_bytes(const RenderParams &p);
-uint32_t wg_regroup_lds_bytes(const RenderParams &p);
 hipError_t wf_intersect_attributes(const RenderParams &p, int *vgprs);
 hipError_t launch_selftest_div(float d, uint32_t lo_bits, uint32_t hi_bits, unsigned long long *d_mismatches, hipStream_t stream);
 hipError_t launch_sum_partials(const float *const *d_partials, uint32_t n, uint32_t n_pixels, float *d_total, hipStream_t stream);
@@ -78,7 +77,6 @@ struct rtr_context {
     uint32_t debug_lds_pad = 0; // option "debug_lds_pad"
     uint32_t block_samples = 8; // option "block_samples": samples of one tile a wave of the samples kernel claims at a time
     uint32_t *d_work = nullptr; // the integrate kernels' ticket counter (one word, zeroed before every launch)
-    int sphere_kernel = 0;           // option "sphere_kernel": 0 auto, 1 wave (k_render), 2 workgroup (k_render_wg)
     bool traversal_counters = false; // option "traversal_counters": tree launches take the counting samples kernel
     bool last_counted = false;       // the most recent launch filled d_work[8 ..]: node steps, leaf tests, SkyMap lookups
     bool stack_wide = false;    // option "stack_entries" = "wide"
@@ -215,7 +213,7 @@ void set_world_params(const rtr_context *ctx, bool enable_bvh_tree, rtr::RenderP
     else if (fs.spheres_only) { p.world = rtr::WORLD_LINEAR_SPHERES; p.stack_cap = 0u; }
     else { p.world = rtr::WORLD_LINEAR_GENERIC; p.stack_cap = fs.mesh_stack_depth + 1u; }
     p.n_objects = fs.n_objects;
-    p.has_volumes = fs.has_volumes ? (fs.has_mesh_volumes ? 2u : 1u) : 0u; // 2: the kernels with the nested mesh walk
+    p.has_volumes = fs.has_volumes ? ((fs.has_mesh_volumes || fs.has_nested_volumes) ? 2u : 1u) : 0u; // 2: the kernels with the nested mesh walk and nested Volumes
     p.has_meshes = fs.n_triangles > 0u ? 1u : 0u;
     p.root_ref = fs.root_ref;
     std::memcpy(p.root_box, fs.root_box, sizeof p.root_box);
@@ -334,15 +332,6 @@ int launch_frame(rtr_context *ctx, const rtr_camera *camera, const rtr_settings 
     // the sphere world, 16 in the tree worlds), and only for launches of at least two tiles per resident wave -- a
     // chunk's workgroups should start after their predecessors have finished, or they spin in each other's way
     // (measured: 1080p/256 spp 18.6 -> 16.9 ms with 4 chunks; 4K, small frames and short sample ranges lose).
-    // "sphere_kernel" = "workgroup": k_render_wg -- four waves per workgroup over four tiles, the paths regrouped by material
-    // kind between world.hit and the rest of trace_ray (whole frames of the linear sphere world in Full mode)
-    p.wg_regroup = (ctx->sphere_kernel == 2 && p.world == rtr::WORLD_LINEAR_SPHERES && p.sphere_regs >= 1u && n_shards == 1u && p.mode == 0u &&
-                    p.max_depth >= 1u && p.max_depth <= 32u && grid > 0u) ? 1u : 0u;
-    if (p.wg_regroup) {
-        grid = (grid + 3u) / 4u; // groups of four tiles
-        lds_bytes = rtr::wg_regroup_lds_bytes(p) + ctx->debug_lds_pad;
-        ctx->last_lds = lds_bytes;
-    }
     p.tiles_launch = grid > 0u ? grid : 1u;
     p.chunks = 1u;
     if (grid > 0u) {
@@ -1101,13 +1090,6 @@ int rtr_set_option(rtr_context *ctx, const char *name, const char *value) {
         if (v == "samples") ctx->multi->split_tiles = false;
         else if (v == "tiles") ctx->multi->split_tiles = true;
         else return fail(ctx, RTR_ERR_INVALID_ARGUMENT, "multi_split must be \"samples\" or \"tiles\"");
-        return RTR_OK;
-    }
-    if (n == "sphere_kernel") { // takes effect at the next render
-        if (v == "auto") ctx->sphere_kernel = 0;
-        else if (v == "wave") ctx->sphere_kernel = 1;
-        else if (v == "workgroup") ctx->sphere_kernel = 2;
-        else return fail(ctx, RTR_ERR_INVALID_ARGUMENT, "sphere_kernel must be \"auto\", \"wave\" or \"workgroup\"");
         return RTR_OK;
     }
     if (n == "traversal_counters") { // takes effect at the next render

@@ -289,10 +289,10 @@ RTR_DEV float poly_log(float xx) {
     return z;
 }
 
-// Volume::hit (lib/volume.rs:34-73) after its two boundary hits t1, t2 (volume.rs:35-36).  Draws one random number per
-// call -- once the clipped interval is known to be non-empty -- exactly where the reference draws it.
-RTR_DEV bool volume_finish(float t1, float t2, float neg_inv_density, float a, float tmax, Rng &rng, float &t) {
-    if (t1 < kTMin) t1 = kTMin;
+// Volume::hit(ray, tmin, tmax) (lib/volume.rs:34-73) after its two boundary hits t1, t2 (volume.rs:35-36).  Draws one random
+// number per call -- once the clipped interval is known to be non-empty -- exactly where the reference draws it.
+RTR_DEV bool volume_finish(float t1, float t2, float neg_inv_density, float a, float tmin, float tmax, Rng &rng, float &t) {
+    if (t1 < tmin) t1 = tmin;
     if (t2 > tmax) t2 = tmax;
     if (t1 >= t2) return false;
     if (t1 < 0.0f) t1 = 0.0f;
@@ -305,11 +305,11 @@ RTR_DEV bool volume_finish(float t1, float t2, float neg_inv_density, float a, f
     return true;
 }
 // ... over a sphere boundary
-RTR_DEV bool volume_t(V3 c, float r2, float neg_inv_density, const Ray &r, float a, float tmax, Rng &rng, float &t) {
+RTR_DEV bool volume_t(V3 c, float r2, float neg_inv_density, const Ray &r, float a, float tmin, float tmax, Rng &rng, float &t) {
     float t1, t2;
     if (!sphere_range(c, r2, r, a, -__builtin_inff(), __builtin_inff(), t1)) return false;
-    if (!sphere_range(c, r2, r, a, t1 + kTMin, __builtin_inff(), t2)) return false;
-    return volume_finish(t1, t2, neg_inv_density, a, tmax, rng, t);
+    if (!sphere_range(c, r2, r, a, t1 + tmin, __builtin_inff(), t2)) return false;
+    return volume_finish(t1, t2, neg_inv_density, a, tmin, tmax, rng, t);
 }
 // mesh.rs:146-184 Moeller-Trumbore with the reference's tests (tmax ignored).
 RTR_DEV bool triangle_t(V3 v0, V3 e1, V3 e2, const Ray &r, float &t, float &u, float &v) {
@@ -495,20 +495,33 @@ RTR_DEV bool accept_tree(const Best &b, float t, uint32_t leaf) {
     return b.leaf == REF_NONE || t < b.t || (!(b.t < t) && (leaf & REF_INDEX) > (b.leaf & REF_INDEX));
 }
 
-// Volume::hit for the Volume leaf record q0..q2 (rtr_device.h): sphere boundary, or a mesh boundary walked on the lane's
-// stack above `sp`.
+// Volume::hit(ray, tmin, tmax) for the Volume leaf record q0..q2 (rtr_device.h) with density word `nid`: sphere boundary, or
+// a mesh boundary walked on the lane's stack above `sp`.
 template <uint32_t VOL>
-RTR_DEV bool volume_leaf_t(const RenderParams &p, const float4 &q0, const float4 &q1, const float4 &q2, const Ray &r, V3 inv, float a,
-                           float tmax, Rng &rng, uint32_t *stk_ref, uint32_t sp, uint32_t lane, float &t) {
-    // VOL == 1: every Volume of the scene has a sphere boundary, and the nested mesh walk is not compiled in (it costs the
+RTR_DEV bool volume_boundary_t(const RenderParams &p, const float4 &q0, const float4 &q1, const float4 &q2, float nid, const Ray &r, V3 inv, float a,
+                               float tmin, float tmax, Rng &rng, uint32_t *stk_ref, uint32_t sp, uint32_t lane, float &t) {
+    // VOL == 1: every Volume of the scene has a sphere boundary, and the nested walks are not compiled in (they cost the
     // launch-bounded tree kernels their register budget); VOL == 2: the leaf record says which
-    if (VOL < 2u || __float_as_uint(q1.z) == 0u) return volume_t(mk(q0.x, q0.y, q0.z), q1.x, q1.y, r, a, tmax, rng, t);
+    if (VOL < 2u || (__float_as_uint(q1.z) & 0xFFu) == 0u) return volume_t(mk(q0.x, q0.y, q0.z), q1.x, nid, r, a, tmin, tmax, rng, t);
     const V3 bmin = mk(q0.x, q0.y, q0.z), bmax = mk(q2.y, q2.z, q2.w);
     const uint32_t root = __float_as_uint(q1.w);
     float t1, t2;
     if (!mesh_range_hit(p.nodes, p.leaf_hot, root, bmin, bmax, r, inv, -__builtin_inff(), __builtin_inff(), stk_ref, sp, lane, t1)) return false;
-    if (!mesh_range_hit(p.nodes, p.leaf_hot, root, bmin, bmax, r, inv, t1 + kTMin, __builtin_inff(), stk_ref, sp, lane, t2)) return false;
-    return volume_finish(t1, t2, q1.y, a, tmax, rng, t);
+    if (!mesh_range_hit(p.nodes, p.leaf_hot, root, bmin, bmax, r, inv, t1 + tmin, __builtin_inff(), stk_ref, sp, lane, t2)) return false;
+    return volume_finish(t1, t2, nid, a, tmin, tmax, rng, t);
+}
+// ... as world.hit reaches it (tmin = 0.00001).  A Volume whose boundary is a Volume (volume.rs:20: any Object; bit 8 of the
+// record's kind word, the inner density in q2.x): the two boundary.hit calls of volume.rs:35-36 are Volume::hit again, with
+// the ranges [-inf, +inf] and [t1 + tmin, +inf] -- each draws its own random number, in call order, before the outer one.
+template <uint32_t VOL>
+RTR_DEV bool volume_leaf_t(const RenderParams &p, const float4 &q0, const float4 &q1, const float4 &q2, const Ray &r, V3 inv, float a,
+                           float tmax, Rng &rng, uint32_t *stk_ref, uint32_t sp, uint32_t lane, float &t) {
+    if (VOL < 2u || (__float_as_uint(q1.z) & 0x100u) == 0u)
+        return volume_boundary_t<VOL>(p, q0, q1, q2, q1.y, r, inv, a, kTMin, tmax, rng, stk_ref, sp, lane, t);
+    float t1, t2;
+    if (!volume_boundary_t<VOL>(p, q0, q1, q2, q2.x, r, inv, a, -__builtin_inff(), __builtin_inff(), rng, stk_ref, sp, lane, t1)) return false;
+    if (!volume_boundary_t<VOL>(p, q0, q1, q2, q2.x, r, inv, a, t1 + kTMin, __builtin_inff(), rng, stk_ref, sp, lane, t2)) return false;
+    return volume_finish(t1, t2, q1.y, a, kTMin, tmax, rng, t);
 }
 
 template <uint32_t VOL>
@@ -1288,7 +1301,12 @@ RTR_DEV bool shade_segment(const RenderParams &p, bool was_hit, const Hit &h, Ra
 // one per resident wave, each claiming tickets until none is left -- 15.1-15.3 ms against 14.05: the same instructions
 // and wave-cycles, but 9 % fewer waves resident on average (in-kernel clocks: waves live 14.3 of the launch's 16.2 ms);
 // and groups of 64 pixels sorted by a cost key from a 4-sample pre-pass instead of 8x8 tiles -- 16.9 ms: 6.6 % MORE
-// wave-cycles in the segment loop (neighbouring pixels are the most coherent company a pixel can have) and a longer tail.
+// wave-cycles in the segment loop (neighbouring pixels are the most coherent company a pixel can have) and a longer tail;
+// and 256-thread workgroups whose four waves deal their 256 paths out anew by material kind between world.hit and the
+// rest of trace_ray, through LDS (counting sort by wave ballots, a 10-word record per path there and back, three barriers
+// per segment; commit 2466776) -- bit-identical, 21.8 ms: the lanes ARE fuller (0.48 -> 0.62 of VALU lane-cycles active)
+// but the sort and exchange bookkeeping adds 197 lane-instructions to a segment's 316, and 40 % of the wave time is
+// spent parked at barriers and LDS waits (22 % in this kernel).
 // First sample (relative) of chunk c of n.  With taper k (0..7) the chunk lengths fall linearly from (8+k)/8 of the mean
 // to (8-k)/8: what is left running when no tickets remain are pieces of the LAST chunk, so that one should be the smallest.
 RTR_DEV uint32_t chunk_boundary(uint32_t count, uint32_t c, uint32_t n, uint32_t taper) {
@@ -1560,242 +1578,6 @@ __global__ __launch_bounds__(64, WORLD == WORLD_LINEAR_SPHERES ? (NS >= 1u && NS
     if (lane < 32u && p.spp > 1u) // scripts/lanestat.py makes 32 one-sample launches first, so slots counter-1..-32 exist
         atomicAdd(p.counter - 1 - lane, (unsigned long long)rtr_lsc[lane]);
 #endif
-    count_segments(nseg, lane);
-}
-
-// ---- sphere world, lanes regrouped by material kind across the waves of a workgroup ---------------------------------
-// In k_render a wave shades its 64 paths where they are: after world.hit ~22 of its lanes have missed, ~20 hit a
-// Lambertian, ~6 a Metal, ~9 a Dielectric, ~2 an Emission sphere (scripts/lanestat.py), and the wave executes every one
-// of those branches -- and the rejection sampler, and the end-of-sample block -- with a fraction of its lanes: the
-// headline kernel does useful work in 35 % of its lane-slots.  Here a workgroup is FOUR waves over four 8x8 tiles, and a
-// segment is two phases with the workgroup's 256 paths dealt out anew in between, through LDS:
-//   A  (home lane = the path's pixel)   world.hit; the lane publishes what the rest of trace_ray needs -- the hit's normal,
-//      the ray's direction, the random stream, the material kind -- in the exchange block;
-//   -- the 256 records are counting-sorted by kind (wave ballots, a 4 x 7 table of counts, one pass of prefix sums) --
-//   B  (executor lane j = the j-th record in kind order)   the rest of trace_ray (render.rs:39-58) for that record: a wave
-//      now holds ONE kind, two where kinds meet; a path that ends is finished there too (attenuation product replayed from
-//      the home lane's chain column, clamp, the next sample's primary ray); the result goes back through the block;
-//   A' (home lane)   adds a finished sample to its pixel's sum (in sample order: a pixel has one sample in flight) or takes
-//      the scattered ray, and goes round.
-// Every path executes exactly the operations it executes in k_render, in the same order, on its own random stream (the
-// executor carries the stream's state there and back): bit-identical frames.  Three workgroup barriers per segment; the
-// chain holds material ids (one word per bounce and path) so that eight waves per SIMD fit the LDS.
-enum PathKind : uint32_t { KIND_MISS = 0u, KIND_EMISSION = 1u, KIND_LAMBERTIAN = 2u, KIND_METAL = 3u, KIND_DIELECTRIC = 4u, KIND_OTHER = 5u, KIND_DEAD = 6u, KIND_COUNT = 7u };
-struct PoolChain { // a path's column of the workgroup's chain block: [entry][256 paths] material ids
-    static constexpr bool kStoresRgb = false;
-    uint32_t *col;
-    uint32_t n;
-    RTR_DEV void push(uint32_t id, V3) { col[n * 256u] = id; n++; }
-    RTR_DEV uint32_t pop() { n--; return col[n * 256u]; }
-    RTR_DEV V3 pop_rgb(const RenderParams &p, const uint32_t *lds_mats) { return material_rgb(p, lds_mats, pop()); }
-    RTR_DEV void reset() { n = 0u; }
-};
-constexpr uint32_t kXchgWords = 10u; // per path: normal 3, direction 3, stream state, stream increment, meta, sample index
-
-// LDS (dynamic): [chain: max_depth x 256][exchange: 10 x 256][perm: 256][counts: 4 x 8][tile origins: 8]
-//                [spheres: NS x 8][slot materials: NS x 8][materials: lds_mats x 8]
-template <uint32_t NS>
-__attribute__((amdgpu_num_sgpr(96)))
-#ifndef RTR_X_WGW
-#define RTR_X_WGW 8
-#endif
-__global__ __launch_bounds__(256, RTR_X_WGW) void k_render_wg(const RenderParams p) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    uint32_t *chain_blk = lds;
-    uint32_t *xchg = chain_blk + p.max_depth * 256u;
-    uint32_t *perm = xchg + kXchgWords * 256u;
-    uint32_t *counts = perm + 256u;          // [wave][8]: kinds 0..6; word 7 of wave 3 broadcasts the ticket
-    uint32_t *origins = counts + 32u;        // [wave]{x0, y0}
-    uint32_t *lds_spheres = origins + 8u;
-    uint32_t *slot_mats = lds_spheres + NS * 8u;
-    uint32_t *lds_mat_base = slot_mats + NS * 8u;
-    const uint32_t *lds_mats = p.lds_materials ? lds_mat_base : nullptr;
-    // stage the small tables (once per workgroup)
-    SphereRegs<NS> sr;
-#pragma unroll
-    for (uint32_t i = 0; i < NS; i++) {
-        const DevLinSphere &sp = p.lin_spheres[i]; // uniform -> scalar loads, kept in SGPRs
-        sr.cx[i] = sp.center[0]; sr.cy[i] = sp.center[1]; sr.cz[i] = sp.center[2]; sr.r2[i] = sp.radius2;
-    }
-    for (uint32_t i = tid; i < NS * 8u; i += 256u) {
-        lds_spheres[i] = reinterpret_cast<const uint32_t *>(p.lin_spheres)[i];
-        slot_mats[i] = reinterpret_cast<const uint32_t *>(p.materials)[p.lin_spheres[i >> 3].material * 8u + (i & 7u)];
-    }
-    for (uint32_t i = tid; i < p.lds_materials * 8u; i += 256u) lds_mat_base[i] = reinterpret_cast<const uint32_t *>(p.materials)[i];
-    __syncthreads();
-    if (tid < NS) { // the two pad words of the sphere table: the radius' prepared reciprocal and its validity
-        const SharedDiv sd = shared_div_prepare(__uint_as_float(lds_spheres[tid * 8u + 3u]));
-        lds_spheres[tid * 8u + 6u] = __float_as_uint(sd.r1);
-        lds_spheres[tid * 8u + 7u] = sd.ok ? 1u : 0u;
-    }
-    Primary cam;
-    cam.init(p);
-    uint32_t nseg = 0;
-
-    if (tid == 0u) counts[31] = atomicAdd(kernarg_params()->work_counter, 1u); // one claim per workgroup, broadcast through LDS
-    __syncthreads();
-    const uint32_t ticket = counts[31];
-    if (ticket < kernarg_params()->work_blocks) { // (workgroup-uniform)
-        // the ticket's four tiles, one per wave: tile = 4 * group + wave
-        const KParams k = kernarg_params();
-        uint32_t chunk, group;
-        ticket_split(k, ticket, chunk, group);
-        const uint32_t tile = group * 4u + wave, tiles_x = k->tiles_x, width = k->width;
-        const uint32_t tx = tile % tiles_x, ty = tile / tiles_x;
-        const uint32_t x = tx * 8u + (lane & 7u), y = ty * 8u + (lane >> 3);
-        const bool inside = tile < k->tiles_total && x < width && y < k->height;
-        const uint32_t pixel = y * width + x; // render.rs:76-77
-        if (lane == 0u) { origins[wave * 2u] = tx * 8u; origins[wave * 2u + 1u] = ty * 8u; }
-        const uint32_t hp = hash32(pixel ^ k->seed_key0);
-        Rng rng;
-        rng.inc = (hash32(hp + k->seed_key1) << 1) | 1u;
-        rng.state = 0u;
-        const uint32_t begin = k->sample_begin, count = k->sample_count, chunks = k->chunks, taper = k->chunk_taper;
-        const uint32_t s_first = begin + chunk_boundary(count, chunk, chunks, taper);
-        const uint32_t s_last = begin + chunk_boundary(count, chunk + 1u, chunks, taper);
-        const uint32_t spp = (inside && k->max_depth > 0u) ? s_last : s_first;
-        V3 acc = mk(0.0f, 0.0f, 0.0f);
-        if (chunk > 0u) { // continue from the sums the previous chunk of this group left behind
-            chunk_wait(k, group, chunk);
-            if (inside) {
-                const float4 c = reinterpret_cast<const float4 *>(k->carry_rgba)[pixel];
-                acc = mk(c.x, c.y, c.z);
-            }
-        }
-        uint32_t s = s_first, depth = 0, chain_n = 0;
-        Ray ray;
-        ray.o = cam.o; ray.d = cam.o;
-        if (s < spp) cam.start(hp, s, (float)x, (float)y, rng, ray);
-        __syncthreads(); // tables, origins
-
-        for (;;) {
-            // ---- A: world.hit at home; publish the record; count the kinds ----
-            const bool alive = s < spp;
-            Hit h;
-            h.point = ray.o; h.normal = ray.o; h.t = 0.0f; h.front_face = false; h.material = 0u; h.slot = 0u;
-            uint32_t kind = KIND_DEAD;
-            if (alive) {
-                nseg++;
-                const bool was_hit = world_hit<WORLD_LINEAR_SPHERES, NS, 0u, false>(p, ray, h, nullptr, nullptr, lane, sr, lds_spheres, rng);
-                if (!was_hit) kind = KIND_MISS;
-                else {
-                    const uint32_t mk_ = slot_mats[h.slot * 8u + 4u]; // the hit sphere's material kind (rtr_material_kind)
-                    kind = mk_ == 0u ? KIND_LAMBERTIAN : mk_ == 1u ? KIND_METAL : mk_ == 2u ? KIND_EMISSION : mk_ == 3u ? KIND_DIELECTRIC : KIND_OTHER;
-                }
-                xchg[0u * 256u + tid] = __float_as_uint(h.normal.x); xchg[1u * 256u + tid] = __float_as_uint(h.normal.y);
-                xchg[2u * 256u + tid] = __float_as_uint(h.normal.z);
-                xchg[3u * 256u + tid] = __float_as_uint(ray.d.x); xchg[4u * 256u + tid] = __float_as_uint(ray.d.y);
-                xchg[5u * 256u + tid] = __float_as_uint(ray.d.z);
-                xchg[6u * 256u + tid] = rng.state; xchg[7u * 256u + tid] = rng.inc;
-                xchg[8u * 256u + tid] = kind | (h.front_face ? 8u : 0u) | (h.slot << 4) | (chain_n << 8) | (depth << 16);
-                xchg[9u * 256u + tid] = s;
-            }
-            uint32_t rank = 0u;
-#pragma unroll
-            for (uint32_t kk = 0; kk < KIND_COUNT; kk++) {
-                const uint64_t m = __ballot(kind == kk);
-                if (kind == kk) rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                if (lane == kk) counts[wave * 8u + kk] = (uint32_t)__popcll(m);
-            }
-            __syncthreads(); // #1: records and counts
-            // ---- deal the records out in kind order ----
-            uint32_t dest = rank, n_live = 0u;
-            {
-                uint32_t before = 0u; // records of smaller kinds, and of my kind in lower waves
-#pragma unroll
-                for (uint32_t kk = 0; kk < KIND_COUNT; kk++) {
-                    uint32_t tot = 0u;
-#pragma unroll
-                    for (uint32_t w = 0; w < 4u; w++) {
-                        const uint32_t c = counts[w * 8u + kk];
-                        if (kk == kind && w < wave) before += c;
-                        tot += c;
-                    }
-                    if (kk < kind) before += tot;
-                    if (kk != KIND_DEAD) n_live += tot;
-                }
-                dest += before;
-            }
-            if (n_live == 0u) break; // (workgroup-uniform)
-            perm[dest] = tid;
-            __syncthreads(); // #2: the order
-            // ---- B: the rest of trace_ray for record j ----
-            if (tid < n_live) {
-                const uint32_t src = perm[tid];
-                Hit g;
-                g.point = mk(0.0f, 0.0f, 0.0f); // (stays at home)
-                g.normal = mk(__uint_as_float(xchg[0u * 256u + src]), __uint_as_float(xchg[1u * 256u + src]), __uint_as_float(xchg[2u * 256u + src]));
-                Ray r2;
-                r2.o = g.point;
-                r2.d = mk(__uint_as_float(xchg[3u * 256u + src]), __uint_as_float(xchg[4u * 256u + src]), __uint_as_float(xchg[5u * 256u + src]));
-                Rng q;
-                q.state = xchg[6u * 256u + src]; q.inc = xchg[7u * 256u + src];
-                const uint32_t meta = xchg[8u * 256u + src];
-                const uint32_t si = xchg[9u * 256u + src];
-                g.t = 0.0f;
-                g.front_face = (meta & 8u) != 0u;
-                g.slot = (meta >> 4) & 15u;
-                g.material = lds_spheres[g.slot * 8u + 5u]; // the sphere's material handle (DevLinSphere)
-                PoolChain chain;
-                chain.col = chain_blk + src;
-                chain.n = (meta >> 8) & 255u;
-                uint32_t d2 = meta >> 16;
-                V3 term;
-                const bool done = shade_segment(p, (meta & 7u) != KIND_MISS, g, r2, q, lds_mats, chain, d2, term, nullptr, slot_mats);
-                uint32_t out_meta = done ? 1u : 0u;
-                V3 o3 = r2.d; // not done: the scattered direction
-                if (done) {
-                    o3 = sample_radiance(p, lds_mats, chain, term); // render.rs:52,95-97: the sample's clamped radiance
-                    if (si + 1u < s_last) { // the pixel's next sample (render.rs:80-90, camera.rs:19-24)
-                        const uint32_t hw = src >> 6, hl = src & 63u;
-                        const uint32_t px = origins[hw * 2u] + (hl & 7u), py = origins[hw * 2u + 1u] + (hl >> 3);
-                        const uint32_t hp2 = hash32((py * p.width + px) ^ p.seed_key0);
-                        Ray r3;
-                        cam.start(hp2, si + 1u, (float)px, (float)py, q, r3);
-                        xchg[3u * 256u + src] = __float_as_uint(r3.d.x); xchg[4u * 256u + src] = __float_as_uint(r3.d.y);
-                        xchg[5u * 256u + src] = __float_as_uint(r3.d.z);
-                        out_meta |= 2u;
-                    }
-                }
-                xchg[0u * 256u + src] = __float_as_uint(o3.x); xchg[1u * 256u + src] = __float_as_uint(o3.y); xchg[2u * 256u + src] = __float_as_uint(o3.z);
-                xchg[6u * 256u + src] = q.state;
-                xchg[8u * 256u + src] = out_meta | (chain.n << 8);
-            }
-            __syncthreads(); // #3: results
-            // ---- A': the home lane takes its result ----
-            if (alive) {
-                const uint32_t meta = xchg[8u * 256u + tid];
-                const V3 o3 = mk(__uint_as_float(xchg[0u * 256u + tid]), __uint_as_float(xchg[1u * 256u + tid]), __uint_as_float(xchg[2u * 256u + tid]));
-                rng.state = xchg[6u * 256u + tid];
-                if (meta & 1u) {
-                    acc = add(acc, o3); // render.rs:99
-                    s++;
-                    depth = 0u; chain_n = 0u;
-                    if (meta & 2u) {
-                        ray.o = cam.o;
-                        ray.d = mk(__uint_as_float(xchg[3u * 256u + tid]), __uint_as_float(xchg[4u * 256u + tid]), __uint_as_float(xchg[5u * 256u + tid]));
-                    }
-                } else {
-                    ray.o = h.point;
-                    ray.d = o3;
-                    depth++;
-                    chain_n = (meta >> 8) & 255u;
-                }
-            }
-        }
-
-        // hand the running sums to the next chunk, or finish the pixels
-        if (chunk + 1u < kernarg_params()->chunks) {
-            if (inside) reinterpret_cast<float4 *>(kernarg_params()->carry_rgba)[pixel] = make_float4(acc.x, acc.y, acc.z, 0.0f);
-            __threadfence();
-            __syncthreads();
-            if (tid == 0u) __hip_atomic_store(kernarg_params()->chunk_flags + group, chunk + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        } else if (inside) {
-            const KParams e = kernarg_params();
-            store_pixel(acc, e->spp, pixel, e->sum_rgba, e->rgba8, e->mean_rgb);
-        }
-    }
     count_segments(nseg, lane);
 }
 
@@ -2521,11 +2303,6 @@ static const void *render_kernel(const RenderParams &p) {
                                          RTR_FN(k_render<WORLD_LINEAR_GENERIC, 0, 2u, true>)};
         return t[v];
     }
-    if (p.wg_regroup) { // option "sphere_kernel" = "workgroup": four waves, paths regrouped by material kind
-        static const void *const g[9] = {nullptr, RTR_FN(k_render_wg<1>), RTR_FN(k_render_wg<2>), RTR_FN(k_render_wg<3>), RTR_FN(k_render_wg<4>),
-                                         RTR_FN(k_render_wg<5>), RTR_FN(k_render_wg<6>), RTR_FN(k_render_wg<7>), RTR_FN(k_render_wg<8>)};
-        return g[p.sphere_regs <= 8u ? p.sphere_regs : 0u];
-    }
     static const void *const t[9] = { // number of spheres held in scalar registers (0 = generic loop)
         RTR_FN(k_render<WORLD_LINEAR_SPHERES, 0, 0u, false>), RTR_FN(k_render<WORLD_LINEAR_SPHERES, 1, 0u, false>),
         RTR_FN(k_render<WORLD_LINEAR_SPHERES, 2, 0u, false>), RTR_FN(k_render<WORLD_LINEAR_SPHERES, 3, 0u, false>),
@@ -2542,19 +2319,16 @@ static const void *wf_shade_kernel(const RenderParams &p) {
     static const void *const t[3] = {RTR_FN(k_wf_shade<0u>), RTR_FN(k_wf_shade<1u>), RTR_FN(k_wf_shade<2u>)};
     return t[vol_level(p)];
 }
-static hipError_t launch_params_kernel(const void *fn, const RenderParams &p, dim3 grid, uint32_t lds_bytes, hipStream_t stream, uint32_t block = 64u) {
+static hipError_t launch_params_kernel(const void *fn, const RenderParams &p, dim3 grid, uint32_t lds_bytes, hipStream_t stream) {
     RenderParams copy = p;
     void *args[] = {&copy};
-    return hipLaunchKernel(fn, grid, dim3(block), args, lds_bytes, stream);
+    return hipLaunchKernel(fn, grid, dim3(64), args, lds_bytes, stream);
 }
 
 hipError_t launch_render(const RenderParams &p, uint32_t grid, uint32_t lds_bytes, hipStream_t stream) {
     const void *fn = render_kernel(p);
     if (!fn) return hipErrorInvalidDeviceFunction;
-    return launch_params_kernel(fn, p, dim3(grid), lds_bytes, stream, p.wg_regroup ? 256u : 64u);
-}
-uint32_t wg_regroup_lds_bytes(const RenderParams &p) { // k_render_wg's layout
-    return (p.max_depth * 256u + kXchgWords * 256u + 256u + 32u + 8u + p.sphere_regs * 16u + p.lds_materials * 8u) * 4u;
+    return launch_params_kernel(fn, p, dim3(grid), lds_bytes, stream);
 }
 
 hipError_t launch_wf_generate(const RenderParams &p, uint32_t batch_samples, hipStream_t stream) {
@@ -2602,7 +2376,7 @@ hipError_t launch_resolve(const float *sum_rgba, uint32_t spp, uint32_t n_pixels
 }
 
 // 64-thread workgroups of the kernel launch_render would take that the current device keeps resident
-uint32_t render_resident_waves(const RenderParams &p, uint32_t lds_bytes) { return resident_waves(render_kernel(p), lds_bytes, p.wg_regroup ? 256 : 64); }
+uint32_t render_resident_waves(const RenderParams &p, uint32_t lds_bytes) { return resident_waves(render_kernel(p), lds_bytes); }
 
 hipError_t render_kernel_attributes(const RenderParams &p, int *vgprs, int *static_lds) {
     hipFuncAttributes attr;
@@ -2621,7 +2395,6 @@ const char *render_kernel_name(const RenderParams &p) {
     if (p.world == WORLD_BVH && p.resumable_walk) return "rtr::k_render_bvh (tree world, resumable walk)";
     if (p.world == WORLD_BVH) return "rtr::k_render<WORLD_BVH> (tree world, wave-synchronous walk)";
     if (p.world == WORLD_LINEAR_GENERIC) return "rtr::k_render<WORLD_LINEAR_GENERIC> (linear world with meshes)";
-    if (p.wg_regroup) return "rtr::k_render_wg<NS> (linear sphere world, paths regrouped by material kind across a 4-wave workgroup)";
     return p.sphere_regs ? "rtr::k_render<WORLD_LINEAR_SPHERES, NS> (linear world, spheres in scalar registers)"
                          : "rtr::k_render<WORLD_LINEAR_SPHERES, 0> (linear world, generic sphere loop)";
 }

@@ -237,6 +237,8 @@ struct Flattener {
     std::vector<uint32_t> &obj_height; // per object: Split nodes on its longest root-to-leaf path
     const std::vector<uint32_t> &obj_leaf_base; // per object: first leaf slot = its rank block in the REFERENCE depth-first order
     const std::vector<uint32_t> &vol_leaf_base; // per volume: first leaf slot of its boundary mesh's triangles (mesh boundaries)
+    const std::vector<bool> &vol_nested;        // per volume: its boundary is a Volume (lowered onto that Volume's boundary)
+    const std::vector<float> &vol_inner_density; // ... whose -1/density this is
     bool leaf_pairs = true;
     std::vector<uint32_t> obj_pushes; // per object: node records on its longest root-to-leaf path
 
@@ -276,6 +278,14 @@ struct Flattener {
             cold.material = s.material;
         }
         hot.f[5] = v.neg_inv_density;
+        if (vol_nested[vi]) { // a Volume inside a Volume: bit 8 of the kind word, the inner Volume's -1/density in the spare word
+            uint32_t kind;
+            std::memcpy(&kind, &hot.f[6], 4);
+            kind |= 0x100u;
+            std::memcpy(&hot.f[6], &kind, 4);
+            hot.f[8] = vol_inner_density[vi];
+            out.has_nested_volumes = true;
+        }
         cold.object = object; cold.handle = 0; // Object::material = boundary.material(), volume.rs:98-100
         out.leaf_hot[L] = hot;
         out.leaf_cold[L] = cold;
@@ -414,13 +424,38 @@ struct Flattener {
 
 } // namespace
 
-int build_flat_scene(const rtr_scene_desc &desc, FlatScene &out, std::string &err, const BuildOptions &opts) {
+int build_flat_scene(const rtr_scene_desc &desc_in, FlatScene &out, std::string &err, const BuildOptions &opts) {
     out = FlatScene{};
-    if ((desc.n_objects && !desc.objects) || (desc.n_spheres && !desc.spheres) || (desc.n_meshes && !desc.meshes) ||
-        (desc.n_materials && !desc.materials) || (desc.n_volumes && !desc.volumes)) {
+    if ((desc_in.n_objects && !desc_in.objects) || (desc_in.n_spheres && !desc_in.spheres) || (desc_in.n_meshes && !desc_in.meshes) ||
+        (desc_in.n_materials && !desc_in.materials) || (desc_in.n_volumes && !desc_in.volumes)) {
         err = "null array with non-zero count in rtr_scene_desc";
         return RTR_ERR_INVALID_ARGUMENT;
     }
+    // ---- Volumes whose boundary is a Volume (lib/volume.rs:20 `boundary: Box<dyn Object>`) ----
+    // Volume::hit asks its boundary twice (volume.rs:35-36); when the boundary is a Volume those two calls are Volume::hit
+    // again, on the inner boundary.  Bounds and material of the outer Volume are the innermost boundary's (volume.rs:90-100),
+    // so the pair lowers to ONE leaf: the inner Volume's sphere or mesh, the OUTER density in the record's usual word and the
+    // inner density beside it (`inner_density`); the kernels evaluate the nested calls.  One level of nesting.
+    std::vector<rtr_volume> vols(desc_in.volumes, desc_in.volumes + desc_in.n_volumes);
+    std::vector<float> inner_density(desc_in.n_volumes, 0.0f);
+    std::vector<bool> nested(desc_in.n_volumes, false), volume_is_object(desc_in.n_volumes, false);
+    for (uint32_t i = 0; i < desc_in.n_objects; i++)
+        if (desc_in.objects[i].kind == RTR_OBJ_VOLUME && desc_in.objects[i].index < desc_in.n_volumes) volume_is_object[desc_in.objects[i].index] = true;
+    for (uint32_t vi = 0; vi < desc_in.n_volumes; vi++) {
+        if (desc_in.volumes[vi].boundary_kind != RTR_OBJ_VOLUME) continue;
+        const uint32_t inner = desc_in.volumes[vi].boundary_mesh; // (the index field names the boundary Volume here)
+        if (inner >= desc_in.n_volumes || inner == vi) { err = "volume boundary volume out of bounds"; return RTR_ERR_BAD_INDEX; }
+        if (desc_in.volumes[inner].boundary_kind == RTR_OBJ_VOLUME) {
+            err = "Volumes nested more than one level deep are outside the GPU path";
+            return RTR_ERR_UNSUPPORTED;
+        }
+        vols[vi] = desc_in.volumes[inner];                       // boundary, bounds and material: the innermost boundary's
+        vols[vi].neg_inv_density = desc_in.volumes[vi].neg_inv_density;
+        inner_density[vi] = desc_in.volumes[inner].neg_inv_density;
+        nested[vi] = true;
+    }
+    rtr_scene_desc desc = desc_in;
+    desc.volumes = vols.data();
     // ---- materials (scene.rs:100-110) ----
     out.materials.resize(desc.n_materials);
     for (uint32_t i = 0; i < desc.n_materials; i++) {
@@ -476,7 +511,7 @@ int build_flat_scene(const rtr_scene_desc &desc, FlatScene &out, std::string &er
     std::vector<MeshBuild> meshes(desc.n_meshes);
     std::vector<bool> bounds_a_volume(desc.n_meshes, false); // such meshes always get the reference's tree (nested walk)
     for (uint32_t vi = 0; vi < desc.n_volumes; vi++)
-        if (desc.volumes[vi].boundary_kind == RTR_OBJ_MESH && desc.volumes[vi].boundary_mesh < desc.n_meshes)
+        if (volume_is_object[vi] && desc.volumes[vi].boundary_kind == RTR_OBJ_MESH && desc.volumes[vi].boundary_mesh < desc.n_meshes)
             bounds_a_volume[desc.volumes[vi].boundary_mesh] = true;
     for (uint32_t mi = 0; mi < desc.n_meshes; mi++) {
         const rtr_mesh &m = desc.meshes[mi];
@@ -620,7 +655,7 @@ int build_flat_scene(const rtr_scene_desc &desc, FlatScene &out, std::string &er
         // the triangles of meshes that bound a Volume: behind the scene tree's leaves (their ranks order ties inside the
         // boundary mesh only)
         for (uint32_t vi = 0; vi < desc.n_volumes; vi++)
-            if (desc.volumes[vi].boundary_kind == RTR_OBJ_MESH && desc.volumes[vi].boundary_mesh < desc.n_meshes) {
+            if (volume_is_object[vi] && desc.volumes[vi].boundary_kind == RTR_OBJ_MESH && desc.volumes[vi].boundary_mesh < desc.n_meshes) {
                 vol_leaf_base[vi] = next;
                 next += desc.meshes[desc.volumes[vi].boundary_mesh].n_tris;
             }
@@ -651,7 +686,7 @@ int build_flat_scene(const rtr_scene_desc &desc, FlatScene &out, std::string &er
     std::vector<uint32_t> obj_ref(desc.n_objects, REF_NONE);
     std::vector<Box> obj_box(desc.n_objects);
     std::vector<uint32_t> obj_height(desc.n_objects, 0);
-    Flattener fl{desc, meshes, scene_walk, out, obj_ref, obj_box, obj_height, obj_leaf_base, vol_leaf_base, true, {}};
+    Flattener fl{desc, meshes, scene_walk, out, obj_ref, obj_box, obj_height, obj_leaf_base, vol_leaf_base, nested, inner_density, true, {}};
     fl.leaf_pairs = opts.leaf_pairs;
     Flattener::Emitted root = fl.emit_scene_node(scene_walk.root);
     out.root_ref = root.ref;

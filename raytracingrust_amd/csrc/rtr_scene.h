@@ -46,6 +46,7 @@ struct FlatScene {
     bool spheres_only = true;
     bool has_volumes = false;   // a Volume leaf exists: traversal must keep the reference's visit set and order
     bool has_mesh_volumes = false; // ... and one of them is bounded by a mesh (nested mesh walk inside Volume::hit)
+    bool has_nested_volumes = false; // ... and one of them is bounded by another Volume (one level: the kernels with the nested mesh walk evaluate it)
     uint32_t n_objects = 0, n_spheres = 0, n_meshes = 0, n_triangles = 0;
 };
 

@@ -162,12 +162,12 @@ class Sphere:
 
 class Volume:
     """lib/volume.rs:19-32: a constant-density medium inside a boundary object (`Volume::new(boundary, density)`
-    stores -1/density).  The boundary is a Sphere or a Mesh (`boundary: Box<dyn Object>`; a Volume inside a Volume is
-    not lowered); its material (normally Isotropic) is the medium's."""
+    stores -1/density).  The boundary is any Object (`boundary: Box<dyn Object>`): a Sphere, a Mesh, or another Volume (the
+    GPU path lowers one level of Volume-in-Volume); its material (normally Isotropic) is the medium's."""
 
-    def __init__(self, boundary: Union["Sphere", "Mesh"], density: float):
-        if not isinstance(boundary, (Sphere, Mesh)):
-            raise TypeError("Volume boundaries are Sphere or Mesh")
+    def __init__(self, boundary: Union["Sphere", "Mesh", "Volume"], density: float):
+        if not isinstance(boundary, (Sphere, Mesh, Volume)):
+            raise TypeError("Volume boundaries are Sphere, Mesh or Volume")
         self.boundary = boundary
         self.density = float(f32(density))
 
@@ -416,13 +416,20 @@ class Scene:
             elif t == "Mesh":
                 raise ValueError("Mesh cannot be deserialized (the reference panics: mesh.rs:51-60)")
             elif t == "Volume":
-                b = o["boundary"]
-                if b.get("type") != "Sphere":
-                    raise ValueError("a Volume over anything but a Sphere cannot be deserialized (Mesh panics in the reference: mesh.rs:51-60)")
-                vol = Volume(Sphere(_xyz(b["center"]), b["radius"], int(b["material"])), 1.0)
-                vol.density = float(f32(-1.0) / f32(o["neg_inv_density"]))
-                vol._neg_inv_density = float(f32(o["neg_inv_density"]))  # keep the stored value bit for bit
-                scene.add_object(vol)
+                def volume_from(d):
+                    b = d["boundary"]
+                    if b.get("type") == "Sphere":
+                        inner = Sphere(_xyz(b["center"]), b["radius"], int(b["material"]))
+                    elif b.get("type") == "Volume":
+                        inner = volume_from(b)
+                    else:
+                        raise ValueError("a Volume over a Mesh cannot be deserialized (Mesh panics in the reference: mesh.rs:51-60)")
+                    vol = Volume(inner, 1.0)
+                    vol.density = float(f32(-1.0) / f32(d["neg_inv_density"]))
+                    vol._neg_inv_density = float(f32(d["neg_inv_density"]))  # keep the stored value bit for bit
+                    return vol
+
+                scene.add_object(volume_from(o))
             else:
                 raise ValueError(f"unknown object type {t!r}")
         return scene
@@ -465,9 +472,16 @@ class Scene:
             if isinstance(o, Sphere):
                 objects.append(sphere(o))
             elif isinstance(o, Volume):
-                if not isinstance(o.boundary, Sphere):
-                    raise ValueError("a Volume over a Mesh cannot be serialized (Mesh panics in the reference: mesh.rs:40-49)")
-                objects.append({"type": "Volume", "boundary": sphere(o.boundary), "neg_inv_density": num(o.neg_inv_density)})
+                def volume_to(v: Volume) -> dict:
+                    if isinstance(v.boundary, Sphere):
+                        b = sphere(v.boundary)
+                    elif isinstance(v.boundary, Volume):
+                        b = volume_to(v.boundary)
+                    else:
+                        raise ValueError("a Volume over a Mesh cannot be serialized (Mesh panics in the reference: mesh.rs:40-49)")
+                    return {"type": "Volume", "boundary": b, "neg_inv_density": num(v.neg_inv_density)}
+
+                objects.append(volume_to(o))
             else:
                 raise ValueError("Mesh cannot be serialized (the reference panics: mesh.rs:40-49)")
         bg = self.background
@@ -565,11 +579,19 @@ class LoweredScene:
     def __init__(self, scene: Scene):
         self._keep = []
         spheres = [o for o in scene.objects if isinstance(o, Sphere)]
-        volumes = [o for o in scene.objects if isinstance(o, Volume)]
+        obj_volumes = [o for o in scene.objects if isinstance(o, Volume)]
+        # volumes[]: the scene's Volume objects, then the Volumes that only bound another Volume (not objects themselves), in
+        # discovery order; a Volume names its boundary Volume by index (boundary_kind = 2)
+        volumes = list(obj_volumes)
+        k = 0
+        while k < len(volumes):
+            if isinstance(volumes[k].boundary, Volume):
+                volumes.append(volumes[k].boundary)
+            k += 1
         # meshes[]: the scene's Mesh objects, then the meshes that only bound a Volume (not objects themselves)
         meshes = [o for o in scene.objects if isinstance(o, Mesh)] + [v.boundary for v in volumes if isinstance(v.boundary, Mesh)]
         n_obj_meshes = sum(isinstance(o, Mesh) for o in scene.objects)
-        if len(spheres) + n_obj_meshes + len(volumes) != len(scene.objects):
+        if len(spheres) + n_obj_meshes + len(obj_volumes) != len(scene.objects):
             raise TypeError("Scene.objects may hold Sphere, Mesh and Volume only")
         vol = (_capi.rtr_volume * max(len(volumes), 1))()
         vi = 0
@@ -596,21 +618,24 @@ class LoweredScene:
                 si += 1
             elif isinstance(o, Volume):
                 objs[i].kind, objs[i].index = 2, vi
-                b = o.boundary
-                if isinstance(b, Sphere):
-                    vol[vi].boundary.center = _capi.c_float3(*[float(x) for x in b.center])
-                    vol[vi].boundary.radius = b.radius
-                    vol[vi].boundary.material = b.material
-                    vol[vi].boundary_kind = 0
-                else:
-                    vol[vi].boundary.material = b.material
-                    vol[vi].boundary_kind, vol[vi].boundary_mesh = 1, bi
-                    bi += 1
-                vol[vi].neg_inv_density = o.neg_inv_density
                 vi += 1
             else:
                 objs[i].kind, objs[i].index = 1, mi
                 mi += 1
+        for vi, o in enumerate(volumes):  # (objects first, boundary-only Volumes behind them)
+            b = o.boundary
+            if isinstance(b, Sphere):
+                vol[vi].boundary.center = _capi.c_float3(*[float(x) for x in b.center])
+                vol[vi].boundary.radius = b.radius
+                vol[vi].boundary.material = b.material
+                vol[vi].boundary_kind = 0
+            elif isinstance(b, Mesh):
+                vol[vi].boundary.material = b.material
+                vol[vi].boundary_kind, vol[vi].boundary_mesh = 1, bi
+                bi += 1
+            else:  # a Volume: named by its index in volumes[]
+                vol[vi].boundary_kind, vol[vi].boundary_mesh = 2, next(j for j, w in enumerate(volumes) if w is b)
+            vol[vi].neg_inv_density = o.neg_inv_density
         lm = scene.lowered_materials()
         mats = (_capi.rtr_material * max(len(lm), 1))()
         for i, m in enumerate(lm):

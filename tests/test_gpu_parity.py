@@ -917,3 +917,45 @@ def test_traversal_counters_against_the_unculled_traversal(builder, w, h):
     assert 0 < st.leaf_tests <= o_st.sphere_tests + o_st.tri_tests
     assert st.node_steps >= st.segments * 0.5  # nearly every segment enters the root
     assert st.sky_lookups == o_st.sky_lookups
+
+
+def _nested_fog_scene(bvh, mesh_boundary, spp=4):
+    """A Volume whose boundary is a Volume (lib/volume.rs:20: `boundary: Box<dyn Object>`), next to ordinary objects."""
+    from raytracingrust_amd.configs import mesh_path
+
+    s = rt.Scene()
+    s.camera = rt.Camera([0.0, 0.6, 3.5], [0.0, 0.0, 0.0], [0.0, 1.0, 0.0], 50.0, 16.0 / 9.0)
+    s.background = rt.GradientBackground([1.0, 1.0, 1.0], [0.4, 0.6, 1.0])
+    s.settings.samples_per_pixel = spp
+    s.settings.enable_bvh_tree = bvh
+    fog = s.add_material(rt.Isotropic([0.9, 0.85, 0.8]))
+    ground = s.add_material(rt.Lambertian([0.4, 0.5, 0.4]))
+    glass = s.add_material(rt.Dielectric(1.5))
+    s.add_object(rt.Sphere([0.0, -101.0, 0.0], 100.0, ground))
+    if mesh_boundary:
+        inner = rt.Volume(rt.Mesh.from_file(mesh_path("cube.obj"), fog), 1.5)
+    else:
+        inner = rt.Volume(rt.Sphere([0.0, 0.0, 0.0], 1.0, fog), 1.5)
+    s.add_object(rt.Volume(inner, 0.8))
+    s.add_object(rt.Sphere([1.8, -0.4, 0.3], 0.6, glass))
+    s.add_object(rt.Volume(rt.Sphere([-1.9, -0.3, 0.2], 0.7, fog), 2.0))  # an ordinary Volume beside it
+    return s
+
+
+@pytest.mark.parametrize("bvh", [True, False])
+@pytest.mark.parametrize("mesh_boundary", [False, True])
+def test_volume_over_a_volume(gpu_renderer, bvh, mesh_boundary):
+    """Volume::hit whose two boundary.hit calls (volume.rs:35-36) are Volume::hit again: three random draws per visit, in
+    call order; bit-identical to the oracle's recursive evaluation, tree and linear worlds, every tree kernel."""
+    scene = _nested_fog_scene(bvh, mesh_boundary)
+    c, st, o_st = run_both(gpu_renderer, scene, 160, 90, 11)
+    assert st.segments == o_st.segments and o_st.rng_draws > 0
+    assert c["mismatched_pixels"] == 0 and c["max_u8_delta"] == 0, c
+    if bvh:
+        ref, _ = gpu_renderer.render(160, 90, seed=11)
+        for kernel in ("samples", "resumable", "wave", "stream"):
+            with rt.Renderer(0) as r:
+                r.set_option("tree_kernel", kernel)
+                r.upload_scene(scene)
+                got, _ = r.render(160, 90, seed=11)
+                assert np.array_equal(got, ref), kernel

@@ -2,6 +2,7 @@
 include/rtr_hip.h declares, host-only contexts refuse to render, the library's BVH builder produces the
 oracle's (= the reference's) tree, and the scene / OBJ readers and the POD lowering behave."""
 import ctypes as C
+import json
 import os
 import re
 
@@ -360,3 +361,32 @@ def test_host_only_multi_context():
     for bad in ([0, -1], [0, 1, 0], []):
         with pytest.raises(rt.RtrError):
             rt.Renderer(bad)
+
+
+def test_volume_over_a_volume_lowers_to_one_leaf():
+    """lib/volume.rs:20 admits any Object as a Volume's boundary.  One level of Volume-in-Volume lowers to a single leaf (the
+    innermost boundary's box and material, volume.rs:90-100) in the library and evaluates recursively in the oracle; deeper
+    chains are outside the GPU path; the typetag JSON round-trips the nesting."""
+    s = rt.Scene()
+    fog = s.add_material(rt.Isotropic([1.0, 1.0, 1.0]))
+    s.add_object(rt.Volume(rt.Volume(rt.Sphere([0, 0, -2], 1.0, fog), 2.0), 3.0))
+    s.add_object(rt.Sphere([2, 0, -2], 0.5, fog))
+    with rt.Renderer(-1) as r:
+        r.upload_scene(s)
+        info = r.scene_info()
+        assert info.n_leaves == 2 and info.n_objects == 2
+    again = rt.Scene.from_dict(json.loads(json.dumps(s.to_dict())))
+    v = again.objects[0]
+    assert isinstance(v, rt.Volume) and isinstance(v.boundary, rt.Volume) and isinstance(v.boundary.boundary, rt.Sphere)
+    assert v.neg_inv_density == s.objects[0].neg_inv_density and v.boundary.neg_inv_density == s.objects[0].boundary.neg_inv_density
+    _, mean, st = pyoracle.OracleScene(s).render(24, 16, 3)
+    _, mean2, st2 = pyoracle.OracleScene(again).render(24, 16, 3)
+    assert st.segments == st2.segments and np.array_equal(mean, mean2)
+    deep = rt.Scene()
+    deep.add_material(rt.Isotropic([1.0, 1.0, 1.0]))
+    deep.add_object(rt.Volume(rt.Volume(rt.Volume(rt.Sphere([0, 0, -2], 1.0, 0), 2.0), 3.0), 4.0))
+    with rt.Renderer(-1) as r:
+        with pytest.raises(rt.RtrError) as e:
+            r.upload_scene(deep)
+        assert e.value.code == -8  # RTR_ERR_UNSUPPORTED
+    assert pyoracle.OracleScene(deep).render(8, 8, 1)[2].segments > 0  # the oracle follows the boxes to any depth
