@@ -68,6 +68,19 @@ RTR_DEV float rt_sqrt(float x) {
     return sqrtf(x);
 }
 
+// The fast half of rt_sqrt alone, for straight-line code: the correctly rounded root when `in_range` comes back true (x in
+// [2^-100, 2^100)), anything otherwise -- the caller has an exact path of its own for those.
+RTR_DEV float rt_sqrt_core(float x, bool &in_range) {
+    const uint32_t b = __float_as_uint(x);
+    in_range = (b - 0x0D800000u) < 0x65000000u;
+    float s = __builtin_amdgcn_sqrtf(x);
+    const float lo = __uint_as_float(__float_as_uint(s) - 1u), hi = __uint_as_float(__float_as_uint(s) + 1u);
+    const float rl = __builtin_fmaf(-lo, s, x), rh = __builtin_fmaf(-hi, s, x);
+    s = rl <= 0.0f ? lo : s;
+    s = rh > 0.0f ? hi : s;
+    return s;
+}
+
 // cgmath normalize = v * (1/|v|)
 RTR_DEV V3 normalize(V3 a) { return scale(a, 1.0f / rt_sqrt(dot(a, a))); }
 
@@ -798,38 +811,33 @@ RTR_DEV bool world_hit(const RenderParams &p, const Ray &r, Hit &h, uint32_t *st
             const float ta_lo = ta * 0x1.ffffep-1f, ta_hi = ta * 0x1.00001p+0f;
             float nb = __builtin_inff(), nb_lo = __builtin_inff(), nb_hi = __builtin_inff();
             bool amb = !safe;
+            // Straight-line code: every sphere's root block runs for every lane, its outcome applied by selects.  A conditional
+            // block per sphere (round 2) skipped the square root for the lanes that miss a sphere, but each block and each
+            // decision inside it cost scalar instructions (exec-mask save / branch / restore: ~100 per trip for the five
+            // spheres against ~50 mask operations now), and scalar instructions are not free on this kernel (60 extra ones per
+            // trip, +20 %, cost +9.7 % of the frame time; 60 extra vector instructions, +10 %, cost +6.0 %); without the branches
+            // the compiler also interleaves the five bodies, which fills the wait states between a compare and the select that
+            // reads it (272 s_nop in the loop before, 8 in this region now).  13.77 -> 13.63 ms on the headline frame.
 #pragma unroll
             for (uint32_t i = 0; i < NS; i++) {
                 V3 oc = sub(r.o, mk(sr.cx[i], sr.cy[i], sr.cz[i]));
                 float half_b = dot(oc, r.d);
                 float cc = dot(oc, oc) - sr.r2[i];
                 float disc = half_b * half_b - a * cc;
-                if (!(disc < 0.0f)) { // objects.rs:31-33 (a NaN discriminant goes on, as in the reference)
-                    RTR_LS(2 + i, true) RTR_LS1(7 + i)
-                    const float sq = rt_sqrt(disc);
-                    const float n1 = -half_b - sq, n2 = -half_b + sq;
-                    float n_acc = n1;
-                    bool acc = false;
-                    if (n1 < ta_lo) {            // first root certainly < tmin: the second root decides
-                        if (n2 < ta_lo || n2 > nb_hi) {
-                            // certainly < tmin, or certainly beyond closest_so_far: None
-                        } else if (n2 > ta_hi && n2 < nb_lo) {
-                            acc = true; n_acc = n2;
-                        } else {
-                            amb = true;
-                        }
-                    } else if (n1 > nb_hi) {
-                        // first root certainly beyond closest_so_far, the second lies farther still: None
-                    } else if (n1 > ta_hi && n1 < nb_lo) {
-                        acc = true;
-                    } else {
-                        amb = true;
-                    }
-                    if (acc) {
-                        nb = n_acc; nb_lo = n_acc * 0x1.ffffep-1f; nb_hi = n_acc * 0x1.00001p+0f;
-                        best = (int)i;
-                    }
-                }
+                const bool on = !(disc < 0.0f); // objects.rs:31-33 (a NaN discriminant goes on, as in the reference)
+                bool fast;                       // disc in the range where rt_sqrt_core is sqrtf (else: the exact scan below)
+                const float sq = rt_sqrt_core(disc, fast);
+                const float n1 = -half_b - sq, n2 = -half_b + sq;
+                const bool c1 = n1 < ta_lo;      // first root certainly < tmin: the second root decides
+                const float n = c1 ? n2 : n1;
+                const bool none = (c1 && n2 < ta_lo) || n > nb_hi; // certainly < tmin, or certainly beyond closest_so_far
+                const bool ok = n > ta_hi && n < nb_lo;            // certainly accepted
+                const bool take = on && fast && !none && ok;
+                amb = amb || (on && (!fast || (!none && !ok)));
+                nb = take ? n : nb;
+                nb_lo = take ? n * 0x1.ffffep-1f : nb_lo;
+                nb_hi = take ? n * 0x1.00001p+0f : nb_hi;
+                best = take ? (int)i : best;
             }
             RTR_LS(25, amb)
             if (!amb) {
