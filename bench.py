@@ -84,6 +84,8 @@ def parse_args(argv=None):
                     help="N GPUs from ONE process through the C ABI's multi-GPU context (rtr_create_multi: a host thread per "
                          "GPU, sample split, ncclReduce and resolve inside librtr_hip.so) instead of one torch.distributed "
                          "rank per GPU; same JSON line")
+    ap.add_argument("--no-traversal-counters", action="store_true",
+                    help="tree worlds: skip the extra counting frame behind roofline.achieved (profiling runs: keeps the dispatch list clean)")
     ap.add_argument("--tree-kernel", default=None, help="rtr_set_option tree_kernel (auto, stream, samples, resumable, wave)")
     return ap.parse_args(argv)
 
@@ -486,7 +488,7 @@ def main():
         alg_bytes = b_seg * seg_per_launch + 4.0 * pixels_per_launch
         prof, prof_status = committed_profile(args, W, H, args.gpus if args.native else world)
         walk = None
-        if scene.settings.enable_bvh_tree and world == 1 and not args.native and not args.tree_kernel:
+        if scene.settings.enable_bvh_tree and world == 1 and not args.native and not args.tree_kernel and not args.no_traversal_counters:
             # one more frame of the last timed seed through the counting instantiation of the samples kernel: what the walk gathered
             r.set_option("traversal_counters", "on")
             r.render_frame_device(W, H, args.seed + args.warmup + args.steps - 1, rgba8.data_ptr(), stream)

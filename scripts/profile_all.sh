@@ -3,11 +3,12 @@
 # configuration, at the kernel sources of this tree.  Through gpurun: bash scripts/profile_all.sh [round-tag]
 # Afterwards, here: copy gpurun_out/profiles_<tag>/* into profiles/<tag>/ and commit.
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
+CONFIGS=${CONFIGS:-"c2 c2b c1 c3 c4 c5"}
 OUT=gpurun_out/profiles_$TAG
 mkdir -p $OUT
-: > $OUT/all_configs.jsonl
-for c in c2 c2b c1 c3 c4 c5; do
+touch $OUT/all_configs.jsonl
+for c in $CONFIGS; do
     if [ $c = c2 ]; then args=""; else args="--config $c"; fi
     bash scripts/profile_bench.sh ${TAG}_$c $args > $OUT/profile_$c.log 2>&1
     cp gpurun_out/prof_${TAG}_$c/*.json $OUT/ 2>/dev/null
@@ -17,7 +18,7 @@ for c in c2 c2b c1 c3 c4 c5; do
 done
 # bench lines AFTER the profiles are in place, so that each line carries its own counters
 mkdir -p profiles/$TAG && cp $OUT/*.json profiles/$TAG/
-for c in c2 c2b c1 c3 c4 c5; do
+for c in $CONFIGS; do
     if [ $c = c2 ]; then args=""; else args="--config $c"; fi
     python bench.py $args --steps 3 --warmup 1 >> $OUT/all_configs.jsonl 2>>$OUT/all_configs.err
     echo "benched $c"

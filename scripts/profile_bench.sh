@@ -5,12 +5,12 @@
 # profiles/<round>/ -- copy both files there and commit them.
 # Usage (through gpurun): bash scripts/profile_bench.sh <tag> [bench args]
 set -u
-TAG=${1:-r02}; shift || true
+TAG=${1:-r03}; shift || true
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-ARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-other-configs $*"
+ARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-other-configs --no-traversal-counters $*"
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 "$ROOT/bench.py" $ARGS > "$OUT/trace.log" 2>&1
 echo "trace rc=$?" >> "$OUT/summary.txt"

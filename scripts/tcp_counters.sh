@@ -7,7 +7,7 @@ ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/tcp_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-ARGS="--steps 2 --warmup 1 --no-cpu-baseline --no-other-configs $*"
+ARGS="--steps 2 --warmup 1 --no-cpu-baseline --no-other-configs --no-traversal-counters $*"
 cd /tmp
 rocprofv3 --pmc TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_READ_sum --output-format csv -d "$OUT/p1" -- python3 "$ROOT/bench.py" $ARGS > "$OUT/p1.log" 2>&1
 rocprofv3 --pmc TCP_TCP_LATENCY_sum TCP_TA_TCP_STATE_READ_sum --output-format csv -d "$OUT/p2" -- python3 "$ROOT/bench.py" $ARGS > "$OUT/p2.log" 2>&1
