@@ -310,6 +310,11 @@ int launch_frame(rtr_context *ctx, const rtr_camera *camera, const rtr_settings 
     }
     // one-word stack entries when every index fits 16 bits (rtr_kernels.hip stack_pack32); option "stack_entries" = "wide" keeps
     // the general form for tests
+    {   // the sphere world's plain case (benchmark.json): k_render's instantiation without the mode / background / mix tests
+        bool plain = p.sphere_regs >= 1u && p.mode == 0u && p.bg_kind == 0u && p.chain_bits != 0xFFFFFFFFu && p.lds_materials > 0u;
+        for (const rtr::DevMaterial &m : fs.materials) plain = plain && m.kind != 4u && m.kind != 5u;
+        p.plain_sphere_world = plain ? 1u : 0u;
+    }
     p.stack_packed = (p.sample_parallel && !streaming && !ctx->stack_wide && fs.nodes.size() <= 65536u && fs.leaf_hot.size() <= 65536u) ? 1u : 0u; // (the samples kernel has both forms)
     uint32_t lds_bytes = p.chain_lds * 64u * 4u + p.stack_cap * 64u * rtr::stack_entry_bytes(p) + (2u * p.sphere_regs + p.lds_materials) * 32u; // spheres, their materials' copies, the material table
     lds_bytes += ctx->debug_lds_pad;

@@ -98,6 +98,8 @@ struct RenderParams {
     uint32_t chain_lds;  // words per lane of the LDS chain region: max_depth ids (3 * max_depth in the sphere world, which keeps
                          // the attenuations themselves), or 0 with chain_bits
     uint32_t sphere_regs;   // linear sphere world: spheres held in scalar registers (0 = generic loop)
+    uint32_t plain_sphere_world; // ... in RenderMode::Full over a UniformBackground, no MixMaterial / Isotropic, attenuations in the chain:
+                            // the instantiation without those wave-uniform tests (shade_segment<PLAIN>)
     uint32_t lds_materials; // number of material records staged in LDS (0 = read from HBM/L1)
     uint32_t has_meshes;    // the scene holds triangles: tree kernels instantiated with the unconditional slab tests
     uint32_t sample_parallel; // WORLD_BVH: k_render_bvh_sp + k_sum_samples

@@ -1073,6 +1073,7 @@ RTR_DEV V3 background(const RenderParams &p, const Ray &r) {
 // The attenuation chain of a path: the ids of the materials whose attenuation multiplies the terminal radiance, in
 // bounce order.  LdsChain: a per-lane column of the wave's LDS, [entry][lane] (conflict-free).  GlobalChain: one u32 per
 // (entry, path) in HBM, [entry][path], for the streaming kernels whose paths outlive a kernel.
+template <bool IDS_POSSIBLE = true> // false: the launch is known to keep attenuations (max_ray_depth <= 16): no id form, no test
 struct LdsChain { // the sphere world's: LDS to spare, nothing to gain from the register form (measured: -2 ... -3 %)
     // Holds the attenuations THEMSELVES (three floats per bounce, [entry][channel][lane]), not material ids: the replay
     // is then one LDS round trip per entry instead of two dependent ones (id, then the material's colour), in the block of
@@ -1083,11 +1084,11 @@ struct LdsChain { // the sphere world's: LDS to spare, nothing to gain from the 
     bool ids; // wave-uniform (RenderParams::chain_bits == 0xFFFFFFFF): fall back to one id per entry when three words per
               // entry would not fit LDS (max_ray_depth above 16; the reference allows 255)
     RTR_DEV void init(uint32_t *lds_base, uint32_t lane_id, uint32_t bits) {
-        base = reinterpret_cast<float *>(lds_base); lane = lane_id; n = 0u; ids = bits == 0xFFFFFFFFu;
+        base = reinterpret_cast<float *>(lds_base); lane = lane_id; n = 0u; ids = IDS_POSSIBLE && bits == 0xFFFFFFFFu;
     }
     RTR_DEV void reset() { n = 0u; }
     RTR_DEV void push(uint32_t id, V3 rgb) {
-        if (ids) {
+        if (IDS_POSSIBLE && ids) {
             reinterpret_cast<uint32_t *>(base)[n * 64u + lane] = id;
         } else {
             float *e = base + n * 192u + lane;
@@ -1097,7 +1098,7 @@ struct LdsChain { // the sphere world's: LDS to spare, nothing to gain from the 
     }
     RTR_DEV V3 pop_rgb(const RenderParams &p, const uint32_t *lds_mats) {
         n--;
-        if (ids) return material_rgb(p, lds_mats, reinterpret_cast<const uint32_t *>(base)[n * 64u + lane]);
+        if (IDS_POSSIBLE && ids) return material_rgb(p, lds_mats, reinterpret_cast<const uint32_t *>(base)[n * 64u + lane]);
         const float *e = base + n * 192u + lane;
         return mk(e[0], e[64], e[128]);
     }
@@ -1174,7 +1175,10 @@ RTR_DEV V3 sample_radiance(const RenderParams &p, const uint32_t *lds_mats, Chai
 
 // The part of trace_ray (render.rs:38-58) after world.hit: background on a miss, else the material's scatter.
 // Returns `done` (the path ended: `term` is its terminal radiance) or false with the next segment in `ray`.
-template <class Chain>
+// PLAIN: the instantiation for launches the host knows to be RenderMode::Full over a UniformBackground with no MixMaterial
+// and no Isotropic in the material table (benchmark.json): the wave-uniform mode / background / mix tests -- scalar
+// compares and branches on every trip -- and the code behind them leave the loop.  Same operations for every path it serves.
+template <bool PLAIN = false, class Chain>
 RTR_DEV bool shade_segment(const RenderParams &p, bool was_hit, const Hit &h, Ray &ray, Rng &rng, const uint32_t *lds_mats,
                            Chain &chain, uint32_t &depth, V3 &term, bool *defer_sky = nullptr, const uint32_t *slot_mats = nullptr) {
     bool done = false;
@@ -1186,9 +1190,18 @@ RTR_DEV bool shade_segment(const RenderParams &p, bool was_hit, const Hit &h, Ra
     {
         if (!was_hit) {
             // defer_sky: the caller evaluates SkyMap::sample later, from the direction (k_render_bvh_sp -> k_sum_samples)
-            if (defer_sky && p.bg_kind == 2u && !p.sky_bilinear) { *defer_sky = true; term = ray.d; }
+            if constexpr (PLAIN) term = ld3(p.bg_a); // UniformBackground::sample, backgrounds.rs:25-30
+            else if (defer_sky && p.bg_kind == 2u && !p.sky_bilinear) { *defer_sky = true; term = ray.d; }
             else term = background(p, ray);
             done = true;
+        } else if (PLAIN) { // Full mode, no MixMaterial: the hit sphere's material record, addressed by the sphere's slot
+            mid = h.material;
+            const float4 *m = reinterpret_cast<const float4 *>(slot_mats + h.slot * 8u);
+            const float4 q0 = m[0], q1 = m[1];
+            kind = __float_as_uint(q1.x);
+            rgb = mk(q0.x, q0.y, q0.z);
+            param = q0.w;
+            mq1 = q1;
         } else if (p.mode == 3u) { // RenderMode::Normal, render.rs:42-45
             V3 n = scale(add(normalize(h.normal), mk(1.0f, 1.0f, 1.0f)), 0.5f);
             term = n;
@@ -1221,7 +1234,7 @@ RTR_DEV bool shade_segment(const RenderParams &p, bool was_hit, const Hit &h, Ra
     // three kinds (one divergent block per segment instead of one per material kind).
     V3 sv = mk(0.0f, 0.0f, 0.0f);
     RTR_LS(13, kind == 0u) RTR_LS(14, kind == 1u) RTR_LS(15, kind == 2u) RTR_LS(16, kind == 3u)
-    const bool need_ball = kind == 0u || kind == 1u || kind == 5u;
+    const bool need_ball = kind == 0u || kind == 1u || (!PLAIN && kind == 5u);
     float m2 = 1.0f;
     if (need_ball) {
 #ifdef RTR_X_LANESTAT
@@ -1475,7 +1488,7 @@ RTR_DEV void ticket_end(uint32_t id, uint32_t lane, uint32_t pixel, V3 acc) {
 
 // One lane = one pixel of the workgroup's ticket.  LDS (dynamic, 16-byte aligned pieces):
 //   [chain: max_depth x 64 u32][stack refs: cap x 64][stack t: cap x 64][spheres: NS x 8][materials: lds_mats x 8]
-template <uint32_t WORLD, uint32_t NS, uint32_t VOL, bool MESH>
+template <uint32_t WORLD, uint32_t NS, uint32_t VOL, bool MESH, bool PLAIN = false>
 // Register budget of the sphere world with up to five spheres in scalar registers (the headline): 8 waves per SIMD -- 64
 // vector registers, and 80 scalar ones (a wave's SGPRs come in 16-register granules out of 800 per SIMD: 96 admit 7
 // waves, 80 admit 8).  Round 2 could not afford it (64 VGPRs only with 51 spilled SGPRs: 14.8 ms against 14.05 at 7 waves);
@@ -1491,7 +1504,7 @@ __global__ __launch_bounds__(64, WORLD == WORLD_LINEAR_SPHERES ? (NS >= 1u && NS
     __builtin_amdgcn_s_waitcnt(0);
     __builtin_amdgcn_wave_barrier();
 #endif
-    typename std::conditional<WORLD == WORLD_LINEAR_SPHERES, LdsChain, PackChain>::type chain;
+    typename std::conditional<WORLD == WORLD_LINEAR_SPHERES, LdsChain<!PLAIN>, PackChain>::type chain;
     chain.init(lds, lane, p.chain_bits);
     uint32_t *stk_ref = lds + p.chain_lds * 64u; // (the sphere world's chain_lds counts three words per entry)
     StackT *stk_t = reinterpret_cast<StackT *>(stk_ref + p.stack_cap * 64u);
@@ -1562,7 +1575,7 @@ __global__ __launch_bounds__(64, WORLD == WORLD_LINEAR_SPHERES ? (NS >= 1u && NS
             V3 term;
             const bool was_hit = world_hit<WORLD, NS, VOL, MESH>(p, ray, h, stk_ref, stk_t, lane, sr, lds_spheres, rng);
             RTR_STAMP(0)
-            const bool done = shade_segment(p, was_hit, h, ray, rng, lds_mats, chain, depth, term, nullptr, slot_mats);
+            const bool done = shade_segment<PLAIN>(p, was_hit, h, ray, rng, lds_mats, chain, depth, term, nullptr, slot_mats);
             RTR_STAMP(1)
             RTR_LS(21, done)
             if (done) {
@@ -2310,6 +2323,15 @@ static const void *render_kernel(const RenderParams &p) {
         static const void *const t[3] = {RTR_FN(k_render<WORLD_LINEAR_GENERIC, 0, 0u, true>), RTR_FN(k_render<WORLD_LINEAR_GENERIC, 0, 1u, true>),
                                          RTR_FN(k_render<WORLD_LINEAR_GENERIC, 0, 2u, true>)};
         return t[v];
+    }
+    if (p.plain_sphere_world) { // Full mode, uniform background, no Mix / Isotropic materials, attenuation chain: shade_segment<PLAIN>
+        static const void *const q[9] = {
+            nullptr, RTR_FN(k_render<WORLD_LINEAR_SPHERES, 1, 0u, false, true>),
+            RTR_FN(k_render<WORLD_LINEAR_SPHERES, 2, 0u, false, true>), RTR_FN(k_render<WORLD_LINEAR_SPHERES, 3, 0u, false, true>),
+            RTR_FN(k_render<WORLD_LINEAR_SPHERES, 4, 0u, false, true>), RTR_FN(k_render<WORLD_LINEAR_SPHERES, 5, 0u, false, true>),
+            RTR_FN(k_render<WORLD_LINEAR_SPHERES, 6, 0u, false, true>), RTR_FN(k_render<WORLD_LINEAR_SPHERES, 7, 0u, false, true>),
+            RTR_FN(k_render<WORLD_LINEAR_SPHERES, 8, 0u, false, true>)};
+        return q[p.sphere_regs <= 8u ? p.sphere_regs : 0u];
     }
     static const void *const t[9] = { // number of spheres held in scalar registers (0 = generic loop)
         RTR_FN(k_render<WORLD_LINEAR_SPHERES, 0, 0u, false>), RTR_FN(k_render<WORLD_LINEAR_SPHERES, 1, 0u, false>),
