@@ -156,7 +156,7 @@ def plumbing_rank(args, world, rank) -> int:
     begin, count = sample_range(rank, world, args.spp)
     w, h = 16, 8
     # stand-in integrate: sample s of pixel p contributes (p + 1) * (s + 1) -- an exact small-integer sum in f32
-    pix = torch.arange(1, w * h + 1, dtype=torch.float32).reshape(h, w, 1).repeat(1, 1, 4)
+    pix = torch.arange(1, w * h + 1, dtype=torch.float32).reshape(h, w, 1).repeat(1, 1, 3)
     part = pix * float(sum(s + 1 for s in range(begin, begin + count)))
     t0 = time.perf_counter()
     for _ in range(args.steps):

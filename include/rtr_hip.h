@@ -320,22 +320,23 @@ int rtr_render_f32(rtr_context *ctx, const rtr_camera *camera, const rtr_setting
 int rtr_render_frame_device(rtr_context *ctx, const rtr_camera *camera, const rtr_settings *settings, uint32_t width,
                             uint32_t height, uint64_t seed, uint8_t *d_rgba8, void *stream);
 /* Sharded integrate: 8x8-pixel tiles t with t % n_shards == shard are rendered; for each of their pixels the
- * sum over samples of the clamped radiance (render.rs:95-99) is STORED to d_sum_rgba[pixel*4 .. +3] (w = 0).
+ * sum over samples of the clamped radiance (render.rs:95-99) is STORED to d_sum_rgb[pixel*3 .. +2] (three floats per
+ * pixel, packed: ABI revision 5; revisions up to 4 stored a padded float4).
  * Pixels of other shards are not touched: zero the buffer first, then a sum over shards (RCCL reduce) is the
  * full frame, bit-identical to the single-GPU sum because x + 0 = x. */
 int rtr_render_tiles_device(rtr_context *ctx, const rtr_camera *camera, const rtr_settings *settings, uint32_t width,
-                            uint32_t height, uint64_t seed, uint32_t shard, uint32_t n_shards, float *d_sum_rgba,
+                            uint32_t height, uint64_t seed, uint32_t shard, uint32_t n_shards, float *d_sum_rgb,
                             void *stream);
 /* Sample-sharded integrate: EVERY pixel, samples [sample_begin, sample_begin + sample_count) of the frame's
- * samples_per_pixel; the in-order sum of their clamped radiance is STORED to d_sum_rgba[pixel*4 .. +3].  The random
+ * samples_per_pixel; the in-order sum of their clamped radiance is STORED to d_sum_rgb[pixel*3 .. +2].  The random
  * streams are keyed by the absolute sample index, so the shards of a frame draw exactly the single-launch numbers;
  * only the order of the float additions across shards differs (a sum of partial sums: ~1e-7 relative).
  * This is the multi-GPU decomposition bench.py uses: every GPU keeps a full grid of short waves (perfect balance). */
 int rtr_render_samples_device(rtr_context *ctx, const rtr_camera *camera, const rtr_settings *settings, uint32_t width,
                               uint32_t height, uint64_t seed, uint32_t sample_begin, uint32_t sample_count,
-                              float *d_sum_rgba, void *stream);
+                              float *d_sum_rgb, void *stream);
 /* mean = sum/spp, sqrt gamma, RGBA8 (render.rs:103-110).  d_rgba8 and/or d_mean_rgb may be NULL. */
-int rtr_resolve_device(rtr_context *ctx, const float *d_sum_rgba, uint32_t samples_per_pixel, uint32_t width,
+int rtr_resolve_device(rtr_context *ctx, const float *d_sum_rgb, uint32_t samples_per_pixel, uint32_t width,
                        uint32_t height, uint8_t *d_rgba8, float *d_mean_rgb, void *stream);
 
 /* Waits for the context's outstanding work, then reports counters and HIP-event timings.  Like rtr_kernel_times_ms

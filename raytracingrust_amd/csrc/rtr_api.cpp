@@ -280,7 +280,7 @@ int launch_frame(rtr_context *ctx, const rtr_camera *camera, const rtr_settings 
     uint32_t tiles_y = (height + 7u) / 8u;
     p.tiles_total = p.tiles_x * tiles_y;
     p.shard = shard; p.n_shards = n_shards;
-    p.sum_rgba = d_sum_rgba; p.rgba8 = d_rgba8; p.mean_rgb = d_mean_rgb;
+    p.sum_rgb = d_sum_rgba; p.rgba8 = d_rgba8; p.mean_rgb = d_mean_rgb;
     const uint32_t slot = ctx->launches % kRing;
     p.counter = ctx->d_counters + slot;
     p.fault = ctx->d_counters + kRing;
@@ -712,7 +712,7 @@ int multi_frame(rtr_context *ctx, const rtr_camera *camera, const rtr_settings *
     if (!ctx->have_scene) return fail(ctx, RTR_ERR_NO_SCENE, "rtr_upload_scene has not been called");
     int rc = check_settings(ctx, camera, st, width, height);
     if (rc) return rc;
-    const size_t bytes = (size_t)width * height * 4u * sizeof(float);
+    const size_t bytes = (size_t)width * height * 3u * sizeof(float); // partial sums: three floats per pixel, packed
     if (m.sum_cap < bytes) { // (re)allocate the partial-sum buffers: waits for the frames in flight
         for (uint32_t r = 0; r < n; r++) { (void)hipSetDevice(ctx->ranks[r]->device); (void)hipDeviceSynchronize(); }
         multi_free_buffers(ctx);
@@ -765,7 +765,7 @@ int multi_frame(rtr_context *ctx, const rtr_camera *camera, const rtr_settings *
             hipStream_t cs = m.comm_stream[r];
             if (!m.same_device) {
                 if (!hip(hipStreamWaitEvent(cs, m.ev_integrated[buf][r], 0), "hipStreamWaitEvent")) return;
-                const ncclResult_t nr = m.rccl.Reduce(sum, r == 0 ? m.d_total[buf] : nullptr, (size_t)width * height * 4u, ncclFloat, ncclSum, 0,
+                const ncclResult_t nr = m.rccl.Reduce(sum, r == 0 ? m.d_total[buf] : nullptr, (size_t)width * height * 3u, ncclFloat, ncclSum, 0,
                                                       m.comms[r], cs);
                 if (nr != ncclSuccess) { out = fail(rk, RTR_ERR_HIP, std::string("ncclReduce: ") + m.rccl.GetErrorString(nr)); return; }
                 if (!hip(hipEventRecord(m.ev_reduced[buf][r], cs), "hipEventRecord")) return;

@@ -146,7 +146,7 @@ struct RenderParams {
     uint32_t wf_depth;    // the depth the launched kernel serves (trace_ray's `depth` argument, render.rs:32)
     uint32_t wf_flush;    // k_wf_intersect: finished walks a wave collects before it stores them and refills the lanes
     // outputs
-    float *sum_rgba;             // float4 per pixel (sharded path) or nullptr
+    float *sum_rgb;              // three floats per pixel, packed (sharded path) or nullptr
     uint8_t *rgba8;              // fused path or nullptr
     float *mean_rgb;             // fused path, optional
     unsigned long long *counter; // segments

@@ -835,8 +835,8 @@ RTR_DEV bool world_hit(const RenderParams &p, const Ray &r, Hit &h, uint32_t *st
                 const bool take = on && fast && !none && ok;
                 amb = amb || (on && (!fast || (!none && !ok)));
                 nb = take ? n : nb;
-                nb_lo = take ? n * 0x1.ffffep-1f : nb_lo;
-                nb_hi = take ? n * 0x1.00001p+0f : nb_hi;
+                nb_lo = nb * 0x1.ffffep-1f; // (of +inf while nothing is accepted: +inf)
+                nb_hi = nb * 0x1.00001p+0f;
                 best = take ? (int)i : best;
             }
             RTR_LS(25, amb)
@@ -1400,8 +1400,10 @@ struct Primary {
 };
 
 // render.rs:103-110 for one pixel: sum / spp, then sqrt gamma and RGBA8 (color.rs:34-41); and / or the bare sum (sharded paths)
-RTR_DEV void store_pixel(V3 acc, uint32_t spp, uint32_t pixel, float *sum_rgba, uint8_t *rgba8, float *mean_rgb) {
-    if (sum_rgba) reinterpret_cast<float4 *>(sum_rgba)[pixel] = make_float4(acc.x, acc.y, acc.z, 0.0f);
+RTR_DEV void store_pixel(V3 acc, uint32_t spp, uint32_t pixel, float *sum_rgb, uint8_t *rgba8, float *mean_rgb) {
+    if (sum_rgb) { // three floats per pixel, packed: what the multi-GPU reduce ships (no padding word on the wire)
+        sum_rgb[3ull * pixel + 0] = acc.x; sum_rgb[3ull * pixel + 1] = acc.y; sum_rgb[3ull * pixel + 2] = acc.z;
+    }
     if (rgba8 || mean_rgb) {
         const float n = (float)spp;
         const V3 mean = mk(acc.x / n, acc.y / n, acc.z / n);
@@ -1482,7 +1484,7 @@ RTR_DEV void ticket_end(uint32_t id, uint32_t lane, uint32_t pixel, V3 acc) {
         if (inside) reinterpret_cast<float4 *>(k->carry_rgba)[pixel] = make_float4(acc.x, acc.y, acc.z, 0.0f);
         chunk_publish(k, tidx, chunk, lane);
     } else if (inside) {
-        store_pixel(acc, k->spp, pixel, k->sum_rgba, k->rgba8, k->mean_rgb);
+        store_pixel(acc, k->spp, pixel, k->sum_rgb, k->rgba8, k->mean_rgb);
     }
 }
 
@@ -2171,24 +2173,21 @@ __global__ __launch_bounds__(256) void k_resolve(const float *sum_rgba, uint32_t
                                                  float *mean_rgb) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_pixels) return;
-    const float4 s = reinterpret_cast<const float4 *>(sum_rgba)[i];
-    store_pixel(mk(s.x, s.y, s.z), spp, i, nullptr, rgba8, mean_rgb);
+    store_pixel(mk(sum_rgba[3ull * i], sum_rgba[3ull * i + 1], sum_rgba[3ull * i + 2]), spp, i, nullptr, rgba8, mean_rgb);
 }
 
 // rtr_create_multi with every rank on ONE device (a test configuration: RCCL cannot put two ranks on one GPU): the ranks'
-// float4 partial sums added in rank order -- what ncclReduce does across GPUs.
-__global__ __launch_bounds__(256) void k_sum_partials(const float *const *partials, uint32_t n, uint32_t n_pixels, float *total) {
+// partial sums (three floats per pixel) added in rank order -- what ncclReduce does across GPUs.
+__global__ __launch_bounds__(256) void k_sum_partials(const float *const *partials, uint32_t n, uint32_t n_floats, float *total) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_pixels) return;
-    float4 acc = reinterpret_cast<const float4 *>(partials[0])[i];
-    for (uint32_t r = 1; r < n; r++) {
-        const float4 v = reinterpret_cast<const float4 *>(partials[r])[i];
-        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
-    }
-    reinterpret_cast<float4 *>(total)[i] = acc;
+    if (i >= n_floats) return;
+    float acc = partials[0][i];
+    for (uint32_t r = 1; r < n; r++) acc += partials[r][i];
+    total[i] = acc;
 }
 hipError_t launch_sum_partials(const float *const *d_partials, uint32_t n, uint32_t n_pixels, float *d_total, hipStream_t stream) {
-    hipLaunchKernelGGL(k_sum_partials, dim3((n_pixels + 255u) / 256u), dim3(256), 0, stream, d_partials, n, n_pixels, d_total);
+    const uint32_t n_floats = n_pixels * 3u;
+    hipLaunchKernelGGL(k_sum_partials, dim3((n_floats + 255u) / 256u), dim3(256), 0, stream, d_partials, n, n_floats, d_total);
     return hipGetLastError();
 }
 

@@ -2,7 +2,7 @@
 
 The frame is cut into 8x8-pixel tiles (one 64-lane wave each, row-major tile index t); rank r of N owns the
 tiles with t % N == r -- interleaving balances sky-heavy and geometry-heavy regions.  Every
-rank integrates its tiles into a zeroed full-frame float4 sum buffer, one `reduce(SUM)` puts the frame on
+rank integrates its tiles into a zeroed full-frame sum buffer (three floats per pixel, packed), one `reduce(SUM)` puts the frame on
 rank 0 (x + 0 = x, so the reduced frame is bit-identical to the single-GPU sums), and rank 0 resolves
 (mean, sqrt gamma, RGBA8: render.rs:103-110).  The random streams are keyed by (seed, pixel, sample), never
 by rank, so the image does not depend on N.
@@ -46,7 +46,7 @@ def sample_range(shard: int, n_shards: int, spp: int):
 def render_frame_distributed(renderer, width: int, height: int, seed: int, accum, rgba8=None, stream: int = 0,
                              group=None, integrate: Optional[Callable] = None, spp: Optional[int] = None,
                              resolve: Optional[Callable] = None):
-    """One frame across the ranks of `group`.  `accum`: this rank's [H, W, 4] float32 tensor (device memory
+    """One frame across the ranks of `group`.  `accum`: this rank's [H, W, 3] float32 tensor (device memory
     for the HIP path); `rgba8`: rank 0's [H, W, 4] uint8 output.  `integrate` / `resolve` default to the HIP
     entry points of `renderer`; the CPU (gloo) tests substitute stand-ins to exercise the sharding and the
     collective without a GPU."""
@@ -98,7 +98,7 @@ class _NullContext:
 class FramePipeline:
     """Double-buffered multi-GPU frames: the RCCL reduce (+ rank 0's resolve) of frame i runs on a communication
     stream while the integrate kernel of frame i+1 runs on the compute stream, so a frame costs
-    max(integrate, reduce) instead of their sum.  Two float4 sum buffers alternate; HIP events order
+    max(integrate, reduce) instead of their sum.  Two packed-RGB sum buffers (12 bytes per pixel: no padding on the wire) alternate; HIP events order
     zero -> integrate -> reduce -> resolve -> reuse.  Results are identical to `render_frame_distributed`.
 
     With `device` = "cpu" the same sequence runs on CPU tensors over whatever backend the process group has (gloo in
@@ -113,7 +113,7 @@ class FramePipeline:
         self.r, self.w, self.h, self.spp, self.group = renderer, width, height, spp, group
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
         self.on_gpu = torch.device(device).type != "cpu"
-        self.accum = [torch.zeros((height, width, 4), dtype=torch.float32, device=device) for _ in range(2)]
+        self.accum = [torch.zeros((height, width, 3), dtype=torch.float32, device=device) for _ in range(2)]  # packed RGB partial sums
         self.rgba8 = torch.zeros((height, width, 4), dtype=torch.uint8, device=device) if self.rank == 0 else None
         if self.on_gpu:
             self.compute = torch.cuda.Stream(device=device)

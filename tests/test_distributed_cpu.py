@@ -46,8 +46,7 @@ def _worker(rank, world, port, w, h, frame_path, out_path):
 
     def integrate(width, height, seed, shard, n_shards, accum):
         mask = torch.from_numpy(rd.owned_pixel_mask(width, height, shard, n_shards))
-        src = torch.zeros((height, width, 4), dtype=torch.float32)
-        src[..., :3] = torch.from_numpy(frame)
+        src = torch.from_numpy(frame).clone()  # [H, W, 3]: packed RGB partial sums
         accum[mask] = src[mask]  # the kernel STOREs its pixels and touches no others
 
     def resolve(accum, spp, rgba8):
@@ -55,7 +54,7 @@ def _worker(rank, world, port, w, h, frame_path, out_path):
         rgba8[..., :3] = torch.clamp(torch.sqrt(mean) * 255.0, 0, 255).to(torch.uint8)
         rgba8[..., 3] = 255
 
-    accum = torch.full((h, w, 4), 123.0)  # garbage: render_frame_distributed must zero it
+    accum = torch.full((h, w, 3), 123.0)  # garbage: render_frame_distributed must zero it
     rgba8 = torch.zeros((h, w, 4), dtype=torch.uint8)
     for _ in range(2):  # twice: the buffer is re-zeroed every frame
         rd.render_frame_distributed(None, w, h, 7, accum, rgba8 if rank == 0 else None, integrate=integrate,
@@ -77,7 +76,7 @@ def test_gloo_sharded_frame_equals_single_frame(tmp_path, world):
     mp.spawn(_worker, args=(world, _free_port(), w, h, frame_path, out_path), nprocs=world, join=True)
     out = np.load(out_path)
     assert np.array_equal(out["accum"][..., :3].view(np.uint32), mean.view(np.uint32))  # bit-identical: x + 0 = x
-    assert np.all(out["accum"][..., 3] == 0)
+    assert out["accum"].shape[-1] == 3  # three floats per pixel on the wire: no padding word
     assert np.all(out["rgba8"][..., 3] == 255)
 
 
@@ -110,8 +109,7 @@ class _StandInRenderer:
         for s in range(begin, begin + count):  # in sample order, as the kernel adds them
             acc = (acc + self.per_sample[s]).astype(np.float32)
         t = self.tensors[ptr]
-        t[..., :3] = torch.from_numpy(acc)
-        t[..., 3] = 0.0
+        t[...] = torch.from_numpy(acc)  # [H, W, 3]: packed RGB partial sums
         self.calls.append((begin, count))
 
     def resolve_device(self, sum_ptr, spp, w, h, rgba_ptr, mean_ptr=0, stream=0):
@@ -171,6 +169,6 @@ def test_gloo_sample_split_pipeline_sums_partial_sums(tmp_path, world):
     if world == 2:
         assert np.array_equal(got, (partial[0] + partial[1]).astype(np.float32))
     assert np.allclose(got, single, rtol=1e-5, atol=1e-7)  # only the order of the float additions differs from one rank
-    assert np.all(out["accum"][..., 3] == 0) and np.all(out["rgba8"][..., 3] == 255)
+    assert out["accum"].shape[-1] == 3 and np.all(out["rgba8"][..., 3] == 255)
     want8 = np.clip(np.sqrt(got / np.float32(spp)) * 255.0, 0, 255).astype(np.uint8)
     assert np.max(np.abs(out["rgba8"][..., :3].astype(int) - want8.astype(int))) <= 1

@@ -112,10 +112,10 @@ def test_sharded_tiles_plus_resolve_equal_fused_frame(gpu_renderer, n_shards):
     rgba_f, mean_f = r.render(w, h, seed=seed, want_rgba8=True, want_mean=True)
     seg_f = r.stats().segments
     dev = torch.device("cuda", 0)
-    total = torch.zeros((h, w, 4), dtype=torch.float32, device=dev)
+    total = torch.zeros((h, w, 3), dtype=torch.float32, device=dev)
     segs = 0
     for shard in range(n_shards):
-        part = torch.zeros((h, w, 4), dtype=torch.float32, device=dev)
+        part = torch.zeros((h, w, 3), dtype=torch.float32, device=dev)
         torch.cuda.synchronize()
         r.render_tiles_device(w, h, seed, shard, n_shards, part.data_ptr(), 0)
         st = r.stats()  # synchronises
@@ -339,13 +339,13 @@ def test_sample_sharded_frame_matches_within_float_sum_order(gpu_renderer, n_sha
     rgba_f, mean_f = r.render(w, h, seed=seed, want_rgba8=True, want_mean=True)
     seg_f = r.stats().segments
     dev = torch.device("cuda", 0)
-    total = torch.zeros((h, w, 4), dtype=torch.float32, device=dev)
+    total = torch.zeros((h, w, 3), dtype=torch.float32, device=dev)
     segs, covered = 0, 0
     for shard in range(n_shards):
         begin, count = sample_range(shard, n_shards, 13)
         assert begin == covered
         covered += count
-        part = torch.full((h, w, 4), 5.0, dtype=torch.float32, device=dev)  # every pixel must be overwritten
+        part = torch.full((h, w, 3), 5.0, dtype=torch.float32, device=dev)  # every pixel must be overwritten
         torch.cuda.synchronize()
         r.render_samples_device(w, h, seed, begin, count, part.data_ptr(), 0)
         segs += r.stats().segments
@@ -678,8 +678,8 @@ def test_sample_chunks_in_the_sharded_paths(gpu_renderer):
     try:
         for chunks in ("1", "3"):
             r.set_option("sample_chunks", chunks)
-            a = torch.zeros((h, w, 4), dtype=torch.float32, device=dev)
-            b = torch.zeros((h, w, 4), dtype=torch.float32, device=dev)
+            a = torch.zeros((h, w, 3), dtype=torch.float32, device=dev)
+            b = torch.zeros((h, w, 3), dtype=torch.float32, device=dev)
             r.render_samples_device(w, h, 5, 6, 11, a.data_ptr(), scene=scene)   # samples [6, 17)
             r.render_tiles_device(w, h, 5, 1, 3, b.data_ptr(), scene=scene)      # shard 1 of 3
             torch.cuda.synchronize()
@@ -707,7 +707,7 @@ def test_sample_parallel_kernel_in_batches_and_sample_shards(gpu_renderer):
             r.set_option("tree_kernel", kernel)
             r.set_option("sample_chunks", chunks)
             r.set_option("samples_batch", batch)
-            a = torch.zeros((h, w, 4), dtype=torch.float32, device=dev)
+            a = torch.zeros((h, w, 3), dtype=torch.float32, device=dev)
             r.render_samples_device(w, h, 9, 3, 8, a.data_ptr(), scene=scene)  # samples [3, 11)
             torch.cuda.synchronize()
             rgba, mean = r.render(w, h, seed=9, want_rgba8=True, want_mean=True)  # the fused path, same options
