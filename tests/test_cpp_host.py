@@ -79,3 +79,20 @@ def test_cpp_gui_scene_matches_python_path(cli, tmp_path, gpu_renderer):
     gpu_renderer.upload_scene(scene)
     _, py_mean = gpu_renderer.render(w, h, seed=seed, want_rgba8=False, want_mean=True)
     assert np.array_equal(mean.view(np.uint32), py_mean.view(np.uint32))
+
+
+@pytest.mark.gpu
+def test_cpp_front_end_over_several_ranks(cli, tmp_path):
+    """`rtr_render --devices 0,0`: rtr::Renderer(std::vector<int>) = rtr_create_multi from C++ (two ranks on the one GPU
+    of this box: the library adds the partial sums itself there).  Sample split: within float addition order of the
+    single-context frame; `--devices 0` (one rank through RCCL): that frame bit for bit."""
+    w, h, spp, seed = 64, 40, 6, 5
+    raws = {}
+    for name, extra in (("single", ["--device", "0"]), ("one_rank", ["--devices", "0"]), ("two_ranks", ["--devices", "0,0"])):
+        raw = str(tmp_path / (name + ".bin"))
+        subprocess.run([cli, "--scene", scene_path("simple.json"), "--width", str(w), "--height", str(h), "--spp", str(spp),
+                        "--seed", str(seed), "--f32", raw, *extra], check=True, capture_output=True, cwd=ROOT)
+        raws[name] = np.fromfile(raw, dtype=np.float32).reshape(h, w, 3)
+    assert np.array_equal(raws["one_rank"].view(np.uint32), raws["single"].view(np.uint32))
+    rel = float(np.linalg.norm(raws["two_ranks"].astype(np.float64) - raws["single"]) / np.linalg.norm(raws["single"].astype(np.float64)))
+    assert rel <= 1e-6, rel
