@@ -84,6 +84,8 @@ struct rtr_context {
     void *d_wf = nullptr;  // streaming wavefront: the path records of one batch (ray, hit, state, chain, stage)
     size_t wf_cap = 0;
     int sample_chunks = 0; // option "sample_chunks": 0 auto, else the number of pieces
+    int chunk_taper = -1;  // option "debug_chunk_taper": -1 auto, else 0..7 (chunk_boundary in rtr_kernels.hip)
+    std::vector<uint32_t> chunk_lengths; // option "debug_chunk_lengths": proportions of the chunks ("15:10:6:1"); sets sample_chunks too
     double chunk_timeout_s = 10.0; // option "chunk_timeout_ms": bound of a sample chunk's wait for its predecessor
     bool sky_bilinear = false;     // option "sky_filter"
     bool debug_fault = false;      // option "debug_fault": the next launches set bit 1 of the fault word
@@ -332,15 +334,19 @@ int launch_frame(rtr_context *ctx, const rtr_camera *camera, const rtr_settings 
         }
         ctx->last_primary = pixels * sample_count;
     }
-    // Sample chunks (rtr_kernels.hip "Sample chunks").  They only pay when the launch is short of work items: auto aims
-    // at ~24 items per resident wave, at most 4 chunks, each long enough to dwarf a workgroup's prologue (64 samples in
-    // the sphere world, 16 in the tree worlds), and only for launches of at least two tiles per resident wave -- a
-    // chunk's workgroups should start after their predecessors have finished, or they spin in each other's way
-    // (measured: 1080p/256 spp 18.6 -> 16.9 ms with 4 chunks; 4K, small frames and short sample ranges lose).
+    // Sample chunks (rtr_kernels.hip "Tickets and sample chunks").  They only pay when the launch is short of work items --
+    // at least two tiles per resident wave, but fewer than ~24 -- so 4K frames take one piece.  Sphere world (round 3, with
+    // the hand-over made of device-scope atomics): few pieces of steeply falling length -- a workgroup's ragged end costs
+    // about as much for a long piece as for a short one, and only the LAST pieces are what the chip drains on.  Headline
+    // frame, proportions a:b:c of the samples: 24:7:1 13.01 ms, 28:3:1 13.00, 20:10:2 13.06, 15:10:6:1 (linear taper 7) 13.11,
+    // 16:8:4:2:1 13.32, 15:1 13.74; 128 samples 24:7:1 6.65 / 7:1 6.73 / one piece 7.41; 64 samples 7:1 3.49 / 24:7:1 3.66 / one
+    // piece 3.80; 32 samples 7:1 1.87 / one piece 2.02 (what a rank of the 2-, 4- and 8-GPU sample split renders).  Tree worlds
+    // (k_render_bvh): up to 4 equal pieces of at least 16 samples.
     p.tiles_launch = grid > 0u ? grid : 1u;
     p.chunks = 1u;
     if (grid > 0u) {
         uint32_t want = 1u;
+        int auto_profile = 0; // sphere world, automatic choice: 1 = proportions 24:7:1, 2 = 7:1
         if (ctx->sample_chunks > 0) {
             want = (uint32_t)ctx->sample_chunks;
         } else if (p.sample_parallel) { // independent work items, no minimum length to speak of: ~80 per resident wave
@@ -349,18 +355,47 @@ int launch_frame(rtr_context *ctx, const rtr_camera *camera, const rtr_settings 
             want = std::min(std::max(1u, 80u * resident / grid), std::max(1u, sample_count / 4u));
         } else {
             const uint32_t resident = std::max(1u, rtr::render_resident_waves(p, lds_bytes));
-            const uint32_t min_len = p.world == rtr::WORLD_LINEAR_SPHERES ? 64u : 16u;
-            uint32_t by_length = sample_count / min_len;
-            // a tapered pair (7/8 + 1/8 of the samples) pays from about 48 samples on (1080p, end of round 2: 32 samples 2.14 ms
-            // in one piece, 2.22 in two; 64 samples 4.04 / 3.82; 128 samples: see DESIGN.md section 6 -- what a rank of the 8-,
-            // 4- and 2-GPU sample split renders)
-            if (p.world == rtr::WORLD_LINEAR_SPHERES && sample_count >= 48u) by_length = std::max(by_length, 2u);
-            if (grid >= 2u * resident) want = std::min(std::min(4u, 24u * resident / grid), by_length);
+            const uint32_t by_length = p.world == rtr::WORLD_LINEAR_SPHERES ? (sample_count >= 96u ? 3u : sample_count >= 24u ? 2u : 1u)
+                                                                            : std::min(4u, sample_count / 16u);
+            if (grid >= 2u * resident) want = std::min(24u * resident / grid, by_length);
+            if (p.world == rtr::WORLD_LINEAR_SPHERES) auto_profile = want == 3u ? 1 : want == 2u ? 2 : 0;
         }
         want = std::max(1u, std::min(want, std::max(1u, sample_count)));
         if ((uint64_t)grid * want > 0x7FFFFFFFull) want = 1u;
         p.chunks = want;
-        p.chunk_taper = p.world == rtr::WORLD_LINEAR_SPHERES ? 6u : 0u; // see chunk_boundary
+        // an explicit chunk count ("sample_chunks"): linear taper, chunk_boundary (headline frame, 4 chunks: taper 4 / 5 / 6 / 7
+        // 13.47 / 13.32 / 13.21 / 13.08 ms)
+        p.chunk_taper = p.world == rtr::WORLD_LINEAR_SPHERES ? 7u : 0u;
+        if (ctx->chunk_taper >= 0) p.chunk_taper = (uint32_t)ctx->chunk_taper;
+        static const std::vector<uint32_t> kThree = {24u, 7u, 1u}, kTwo = {7u, 1u};
+        const std::vector<uint32_t> &lengths = ctx->chunk_lengths.size() == want ? ctx->chunk_lengths
+                                               : (auto_profile == 1 && want == 3u) ? kThree
+                                               : (auto_profile == 2 && want == 2u) ? kTwo : ctx->chunk_lengths;
+        // the boundaries of up to eight chunks go to the kernel as a table (chunk_boundary in rtr_kernels.hip: the same
+        // linear taper; any boundaries give the same frame), or come from option "debug_chunk_lengths"
+        p.chunk_table_on = 0u;
+        if (want <= 8u && !p.sample_parallel) {
+            const bool given = lengths.size() == want;
+            uint64_t sum_given = 0;
+            for (uint32_t v : lengths) sum_given += v;
+            for (uint32_t c = 0; c <= want; c++) {
+                uint64_t first;
+                if (given) {
+                    uint64_t before = 0;
+                    for (uint32_t i = 0; i < c; i++) before += lengths[i];
+                    first = (uint64_t)sample_count * before / std::max<uint64_t>(sum_given, 1ull); // lengths are proportions
+                } else if (p.chunk_taper == 0u || want < 2u) {
+                    first = (uint64_t)sample_count * c / want;
+                } else {
+                    const uint64_t k = p.chunk_taper, n = want;
+                    const uint64_t num = (uint64_t)c * (8u + k) * (n - 1u) - k * (uint64_t)c * (c - 1u);
+                    first = (uint64_t)sample_count * num / (8ull * n * (n - 1u));
+                }
+                p.chunk_first[c] = (uint32_t)first;
+            }
+            p.chunk_first[want] = sample_count;
+            p.chunk_table_on = 1u;
+        }
     }
     // Per-sample radiance buffer of the "samples" and "stream" tree kernels: sample_count * W * H float4, filled in
     // batches ("stream" adds its path records: 65 + 4 * max_ray_depth bytes per path of the batch).  A batch takes at
@@ -740,7 +775,7 @@ int multi_frame(rtr_context *ctx, const rtr_camera *camera, const rtr_settings *
     }
     for (uint32_t r = 0; r < n; r++) {
         rtr_context *rk = ctx->ranks[r];
-        rk->tree_kernel = ctx->tree_kernel; rk->sample_chunks = ctx->sample_chunks; rk->block_samples = ctx->block_samples;
+        rk->tree_kernel = ctx->tree_kernel; rk->sample_chunks = ctx->sample_chunks; rk->chunk_taper = ctx->chunk_taper; rk->chunk_lengths = ctx->chunk_lengths; rk->block_samples = ctx->block_samples;
         rk->samples_batch = ctx->samples_batch; rk->stack_wide = ctx->stack_wide; rk->sky_bilinear = ctx->sky_bilinear;
         rk->chunk_timeout_s = ctx->chunk_timeout_s; rk->wf_flush = ctx->wf_flush; rk->debug_fault = ctx->debug_fault;
         rk->traversal_counters = ctx->traversal_counters;
@@ -1042,6 +1077,29 @@ int rtr_set_option(rtr_context *ctx, const char *name, const char *value) {
         const unsigned long k = std::strtoul(v.c_str(), &end, 10);
         if (v.empty() || *end != '\0' || k < 1ul || k > 4096ul) return fail(ctx, RTR_ERR_INVALID_ARGUMENT, "sample_chunks must be \"auto\" or an integer in [1, 4096]");
         ctx->sample_chunks = (int)k;
+        return RTR_OK;
+    }
+    if (n == "debug_chunk_lengths") { // measuring aid: relative chunk lengths, e.g. "24:7:1" (any values give the same frame)
+        std::vector<uint32_t> lens;
+        size_t pos = 0;
+        while (pos <= v.size()) {
+            const size_t colon = std::min(v.find(':', pos), v.size());
+            char *end = nullptr;
+            const std::string item = v.substr(pos, colon - pos);
+            const unsigned long k = std::strtoul(item.c_str(), &end, 10);
+            if (item.empty() || *end != '\0' || k < 1ul || k > 65536ul) return fail(ctx, RTR_ERR_INVALID_ARGUMENT, "debug_chunk_lengths must be 1..8 positive integers separated by ':'");
+            lens.push_back((uint32_t)k);
+            pos = colon + 1;
+        }
+        if (lens.empty() || lens.size() > 8u) return fail(ctx, RTR_ERR_INVALID_ARGUMENT, "debug_chunk_lengths must be 1..8 positive integers separated by ':'");
+        ctx->chunk_lengths = lens;
+        ctx->sample_chunks = (int)lens.size();
+        return RTR_OK;
+    }
+    if (n == "debug_chunk_taper") { // measuring aid: how steeply the chunk lengths fall (any value gives the same frame)
+        if (v == "auto") { ctx->chunk_taper = -1; return RTR_OK; }
+        if (v.size() != 1 || v[0] < '0' || v[0] > '7') return fail(ctx, RTR_ERR_INVALID_ARGUMENT, "debug_chunk_taper must be \"auto\" or 0..7");
+        ctx->chunk_taper = v[0] - '0';
         return RTR_OK;
     }
     if (n == "chunk_timeout_ms") { // takes effect at the next render

@@ -130,6 +130,8 @@ struct RenderParams {
     uint32_t tiles_launch;  // tiles this launch renders (shard, shard + n_shards, ...): grid = tiles_launch * chunks
     uint32_t chunks;        // pieces every pixel's sample range is cut into (>= 1); tickets are chunk-major
     uint32_t chunk_taper;   // 0: equal pieces; k in 1..7: lengths fall linearly from (8+k)/8 to (8-k)/8 of the mean
+    uint32_t chunk_table_on; // 1: chunks <= 8 and chunk c covers samples [chunk_first[c], chunk_first[c + 1]) of the launch's range
+    uint32_t chunk_first[9]; //    (filled by the host: no 64-bit divisions in a workgroup's prologue); 0: chunk_boundary(), any count
     float *carry_rgba;      // float4 running sums handed from chunk to chunk (chunks > 1)
     float *samples;         // k_render_bvh_sp: float4 [sample - sample_begin][pixel], one clamped radiance per sample
     uint32_t *chunk_flags;  // per launch-local tile: chunks completed (chunks > 1)

@@ -29,8 +29,8 @@ namespace rtr {
 #ifdef RTR_X_LANESTAT // diagnostic build only (scripts/lanestat.py): lanes active per block of the headline kernel's loop
 __shared__ uint32_t rtr_lsc[32];
 #define RTR_LS(k, cond) { const uint64_t m_ = __ballot(cond); \
-        if (m_ && lane == (uint32_t)(__ffsll((long long)m_) - 1)) atomicAdd(&rtr_lsc[k], (uint32_t)__popcll(m_)); }
-#define RTR_LS1(k) { const uint64_t m_ = __ballot(true); if (lane == (uint32_t)(__ffsll((long long)m_) - 1)) atomicAdd(&rtr_lsc[k], 1u); }
+        if (m_ && (threadIdx.x & 63u) == (uint32_t)(__ffsll((long long)m_) - 1)) atomicAdd(&rtr_lsc[k], (uint32_t)__popcll(m_)); }
+#define RTR_LS1(k) { const uint64_t m_ = __ballot(true); if ((threadIdx.x & 63u) == (uint32_t)(__ffsll((long long)m_) - 1)) atomicAdd(&rtr_lsc[k], 1u); }
 #else
 #define RTR_LS(k, cond)
 #define RTR_LS1(k)
@@ -1343,18 +1343,41 @@ RTR_DEV void chunk_wait(KParams p, uint32_t tidx, uint32_t chunk) {
     // context's sticky fault word, which every synchronising entry point of the C ABI turns into RTR_ERR_HIP
     // (rtr_api.cpp check_fault).
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-    while (__hip_atomic_load(p->chunk_flags + tidx, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < chunk) {
+    while (__hip_atomic_load(p->chunk_flags + tidx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < chunk) {
         __builtin_amdgcn_s_sleep(16);
         if (__builtin_amdgcn_s_memrealtime() - t0 > p->chunk_timeout_ticks) {
             if (threadIdx.x == 0) atomicOr(p->fault, 1ull);
             break;
         }
     }
+    asm volatile("" ::: "memory"); // the carry loads are issued after the counter has been seen (the loop's own vmcnt(0))
 }
 RTR_DEV void chunk_publish(KParams p, uint32_t tidx, uint32_t chunk, uint32_t lane) {
-    __threadfence(); // the wave's carry stores are visible device-wide before the counter moves
+    // the wave's carry stores have completed before the counter moves (a one-wave workgroup's fence compiles to nothing)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
-    if (lane == 0) __hip_atomic_store(p->chunk_flags + tidx, chunk + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    if (lane == 0) __hip_atomic_store(p->chunk_flags + tidx, chunk + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// The hand-over's memory traffic is made of device-scope atomic accesses only -- the carry words and the counter are written
+// and read with relaxed agent-scope atomics, which gfx950 performs at the device's coherence point (`sc1`: write-through
+// stores, loads that do not trust the XCD's L2) -- ordered by the wave's own completion counter (`s_waitcnt vmcnt(0)`: a wait, no cache operation).  Round 2 / early round 3 used plain stores with __threadfence() + a
+// release store, and an acquire load: on a GPU of eight L2s an agent-scope release writes back the XCD's whole L2
+// (`buffer_wbl2 sc1`, twice per hand-over here) and an acquire invalidates it (`buffer_inv sc1`), for every workgroup of
+// the launch, under everybody else's feet: chunk counts above four cost far more than their prologues (8 chunks: 15.2 ms
+// against 13.2) and the frame itself paid for ~97 000 such pairs.
+RTR_DEV V3 carry_load(KParams p, uint32_t pixel) {
+    const float *c = p->carry_rgba + 4ull * pixel;
+    V3 v;
+    v.x = __hip_atomic_load(c + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    v.y = __hip_atomic_load(c + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    v.z = __hip_atomic_load(c + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return v;
+}
+RTR_DEV void carry_store(KParams p, uint32_t pixel, V3 v) {
+    float *c = p->carry_rgba + 4ull * pixel;
+    __hip_atomic_store(c + 0, v.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(c + 1, v.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(c + 2, v.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // The workgroup's ticket (wave-uniform); false when the launch has more workgroups than tickets.  (Only the ticket's number
 // stays live across the segment loop; chunk and tile are divided out of it again where the ticket ends.)
@@ -1458,8 +1481,14 @@ RTR_DEV TicketLane ticket_begin(uint32_t id, uint32_t lane) {
     // samples [sample_begin, sample_begin + sample_count) of this pixel; the random stream is keyed by the
     // absolute sample index, so a frame split by samples over several launches / GPUs draws the same numbers
     const uint32_t begin = k->sample_begin, count = k->sample_count, chunks = k->chunks, taper = k->chunk_taper;
-    t.s_first = begin + chunk_boundary(count, chunk, chunks, taper);
-    const uint32_t s_last = begin + chunk_boundary(count, chunk + 1u, chunks, taper);
+    uint32_t s_last;
+    if (k->chunk_table_on) { // the host's table (rtr_api.cpp): up to eight chunks
+        t.s_first = begin + k->chunk_first[chunk];
+        s_last = begin + k->chunk_first[chunk + 1u];
+    } else {
+        t.s_first = begin + chunk_boundary(count, chunk, chunks, taper);
+        s_last = begin + chunk_boundary(count, chunk + 1u, chunks, taper);
+    }
     // (per lane on purpose: the wave-uniform form -- lanes off the frame's edge starting at s_last -- saves a register
     // and measured 0.8 % slower)
     t.s_end = (inside && k->max_depth > 0u) ? s_last : t.s_first;
@@ -1467,8 +1496,7 @@ RTR_DEV TicketLane ticket_begin(uint32_t id, uint32_t lane) {
     if (chunk > 0u) { // continue from the sums the previous chunk of this group left behind
         chunk_wait(k, tidx, chunk);
         if (inside) {
-            const float4 c = reinterpret_cast<const float4 *>(k->carry_rgba)[t.pixel];
-            t.acc = mk(c.x, c.y, c.z);
+            t.acc = carry_load(k, t.pixel);
         }
     }
     if (!inside) t.pixel = 0xFFFFFFFFu;
@@ -1481,7 +1509,7 @@ RTR_DEV void ticket_end(uint32_t id, uint32_t lane, uint32_t pixel, V3 acc) {
     ticket_split(k, id, chunk, tidx);
     const bool inside = pixel != 0xFFFFFFFFu;
     if (chunk + 1u < k->chunks) {
-        if (inside) reinterpret_cast<float4 *>(k->carry_rgba)[pixel] = make_float4(acc.x, acc.y, acc.z, 0.0f);
+        if (inside) carry_store(k, pixel, acc);
         chunk_publish(k, tidx, chunk, lane);
     } else if (inside) {
         store_pixel(acc, k->spp, pixel, k->sum_rgb, k->rgba8, k->mean_rgb);
@@ -1501,6 +1529,10 @@ __attribute__((amdgpu_num_sgpr(96))) // (the cap of the 7-wave instantiations; a
 __global__ __launch_bounds__(64, WORLD == WORLD_LINEAR_SPHERES ? (NS >= 1u && NS <= 5u ? 8 : 7) : 1) void k_render(const RenderParams p) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const uint32_t lane = threadIdx.x;
+#ifdef RTR_X_LIFE // diagnostic build only (scripts/wave_life.py): how long the launch's workgroups live, and how long before their loop
+    const unsigned long long life_t0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long life_t1 = life_t0;
+#endif
 #ifdef RTR_X_LANESTAT
     if (lane < 32u) rtr_lsc[lane] = 0u;
     __builtin_amdgcn_s_waitcnt(0);
@@ -1567,6 +1599,10 @@ __global__ __launch_bounds__(64, WORLD == WORLD_LINEAR_SPHERES ? (NS >= 1u && NS
         Ray ray;
         ray.o = cam.o; ray.d = cam.o;
         if (s < spp) { cam.start(hp, s, fx, fy, rng, ray); chain.reset(); }
+#ifdef RTR_X_LIFE
+        __builtin_amdgcn_s_waitcnt(0);
+        life_t1 = __builtin_amdgcn_s_memrealtime();
+#endif
 
         while (s < spp) {
             RTR_STAMP(4)
@@ -1591,6 +1627,17 @@ __global__ __launch_bounds__(64, WORLD == WORLD_LINEAR_SPHERES ? (NS >= 1u && NS
 
         ticket_end(ticket, lane, pixel, acc);
     }
+#ifdef RTR_X_LIFE
+    if (p.spp > 1u) { // scripts/wave_life.py makes 3 one-sample launches first, so slots counter-1..-3 exist
+        __builtin_amdgcn_s_waitcnt(0);
+        const unsigned long long life_t2 = __builtin_amdgcn_s_memrealtime();
+        if (lane == 0) {
+            atomicAdd(p.counter - 1, life_t2 - life_t0); // lifetimes, in 10 ns
+            atomicAdd(p.counter - 2, life_t1 - life_t0); // before the loop
+            atomicAdd(p.counter - 3, 1ull);              // workgroups
+        }
+    }
+#endif
 #ifdef RTR_X_STAMPS
     if (lane == 0 && p.spp > 1u) // scripts/stamps.py makes 5 one-sample launches first, so slots counter-1..-5 exist
         for (int k = 0; k < 5; k++) atomicAdd(p.counter - 1 - k, st_acc[k]);

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Diagnostic: lanes active per block of the headline kernel's loop, from a -DRTR_X_LANESTAT build (never the product).
-usage (on the GPU box): python scripts/lanestat.py [config] [spp] [WxH]"""
+usage (on the GPU box): python scripts/lanestat.py [config] [spp] [WxH] [sample_chunks]"""
 import copy
 import os
 import sys
@@ -17,7 +17,7 @@ scene, W, H = baseline_config(cfg, spp)
 if len(sys.argv) > 3:
     W, H = (int(v) for v in sys.argv[3].split("x"))
 r = rt.Renderer(0)
-r.set_option("sample_chunks", "1")
+r.set_option("sample_chunks", sys.argv[4] if len(sys.argv) > 4 else "1")
 r.upload_scene(scene)
 one = copy.copy(scene)
 one.settings = copy.copy(scene.settings)

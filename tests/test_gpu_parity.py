@@ -654,9 +654,18 @@ def test_sample_chunks_do_not_change_a_bit(builder, w, h):
             r.set_option("sample_chunks", chunks)
             rgba, mean = r.render(w, h, seed=19, want_rgba8=True, want_mean=True)
             frames.append((rgba, mean.view(np.uint32).copy(), r.stats().segments))
+        # the pieces' lengths: the linear taper of an explicit count, or given proportions (what "auto" picks on large frames)
+        for name, value in (("debug_chunk_taper", "0"), ("debug_chunk_taper", "7"), ("debug_chunk_lengths", "24:7:1"),
+                            ("debug_chunk_lengths", "7:1"), ("debug_chunk_lengths", "1:1:1:1:1:1:1:40"), ("debug_chunk_lengths", "1:900")):
+            r.set_option(name, value)
+            rgba, mean = r.render(w, h, seed=19, want_rgba8=True, want_mean=True)
+            frames.append((rgba, mean.view(np.uint32).copy(), r.stats().segments))
         for bad in ("0", "4097", "many", ""):
             with pytest.raises(rt.RtrError):
                 r.set_option("sample_chunks", bad)
+        for bad in ("", "0:1", "1:2:3:4:5:6:7:8:9", "3:x"):
+            with pytest.raises(rt.RtrError):
+                r.set_option("debug_chunk_lengths", bad)
     for rgba, mean_bits, seg in frames[1:]:
         assert seg == frames[0][2]
         assert np.array_equal(rgba, frames[0][0]) and np.array_equal(mean_bits, frames[0][1])

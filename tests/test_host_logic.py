@@ -282,6 +282,7 @@ def test_options_are_validated_without_a_device():
                                 ("stream_flush", ["1", "64", "8"], "0"),
                                 ("samples_batch", ["3", "0"], "-1"),
                                 ("sample_chunks", ["1", "7", "auto"], "0"),
+                                ("debug_chunk_taper", ["0", "7", "auto"], "8"), ("debug_chunk_lengths", ["24:7:1", "5"], "3::1"),
                                 ("chunk_timeout_ms", ["0", "2.5", "10000"], "-1"), ("debug_fault", ["on", "off"], "1"),
                                 ("debug_alloc_limit", ["4096", "0"], "lots"),
                                 ("sky_filter", ["bilinear", "nearest"], "cubic"),
