@@ -6,7 +6,7 @@
 //                box of the root lives in the launch parameters.  Leaves (bvh.rs `Object(u32)`) have no
 //                box in the reference and none here.
 //   leaf_hot[]   48 B per leaf, indexed by the leaf's rank L in the reference's depth-first order
-//                (left before right, bvh.rs:162-163).  Sphere: centre, radius, radius^2.
+//                (left before right, bvh.rs:162-163).  Sphere: centre, radius^2 (one 16-byte load per test), radius.
 //                Triangle: v0, e1 = v1-v0, e2 = v2-v0 (mesh.rs:160-161, hoisted: pure functions).
 //                Volume: boundary centre, radius, radius^2, -1/density (volume.rs:19-32).
 //   leaf_cold[]  64 B per leaf, read once per segment for the winning leaf only: vertex normals,

@@ -446,7 +446,6 @@ RTR_DEV void gather_fence(const float4 &a, const float4 &b, const float4 &c, con
 RTR_DEV void gather_fence(const float4 &a, const float4 &b, float c) {
     asm volatile("" ::"v"(a.x), "v"(a.y), "v"(a.z), "v"(a.w), "v"(b.x), "v"(b.y), "v"(b.z), "v"(b.w), "v"(c));
 }
-RTR_DEV void gather_fence(const float4 &a, float b) { asm volatile("" ::"v"(a.x), "v"(a.y), "v"(a.z), "v"(a.w), "v"(b)); }
 RTR_DEV void gather_fence(const float4 &a, const float4 &b, const float4 &c, const float4 &d) {
     asm volatile("" ::"v"(a.x), "v"(a.y), "v"(a.z), "v"(a.w), "v"(b.x), "v"(b.y), "v"(b.z), "v"(b.w), "v"(c.x), "v"(c.y), "v"(c.z), "v"(c.w),
                  "v"(d.x), "v"(d.y), "v"(d.z), "v"(d.w));
@@ -564,12 +563,10 @@ RTR_DEV void test_leaf(const RenderParams &p, uint32_t ref, const Ray &r, V3 inv
             best_take(best, t, ref);
         }
     } else {
-        const float4 q0 = hot[0]; // centre, radius
-        const float r2 = reinterpret_cast<const float *>(hot)[4];
-        gather_fence(q0, r2);
+        const float4 q0 = hot[0]; // centre, radius^2: one load (the radius itself is the record's fifth word, read by finish_leaf)
         float t;
         // Sphere::hit(ray, tmin, +inf) as called from the tree (bvh.rs:156)
-        if (sphere_t(mk(q0.x, q0.y, q0.z), r2, r, a, __builtin_inff(), t) && accept_tree(best, t, ref)) {
+        if (sphere_t(mk(q0.x, q0.y, q0.z), q0.w, r, a, __builtin_inff(), t) && accept_tree(best, t, ref)) {
             best_take(best, t, ref);
         }
     }
@@ -771,8 +768,9 @@ RTR_DEV void finish_leaf(const RenderParams &p, const Best &best, const Ray &r, 
         face_forward(h, r, mk(1.0f, 0.0f, 0.0f)); // volume.rs:67: the arbitrary constant normal
     } else {
         const float4 *hot = reinterpret_cast<const float4 *>(p.leaf_hot + L);
-        float4 q0 = hot[0];
-        V3 outward = divs(sub(h.point, mk(q0.x, q0.y, q0.z)), q0.w);
+        const float4 q0 = hot[0];
+        const float radius = reinterpret_cast<const float *>(hot)[4];
+        V3 outward = divs(sub(h.point, mk(q0.x, q0.y, q0.z)), radius);
         face_forward(h, r, outward);
     }
 }
@@ -918,7 +916,7 @@ RTR_DEV bool world_hit(const RenderParams &p, const Ray &r, Hit &h, uint32_t *st
                     float4 q0 = hot[0], q1 = hot[1], q2 = hot[2];
                     float t;
                     const bool got = (VOL && (ref & REF_VOL)) ? volume_leaf_t<VOL>(p, q0, q1, q2, r, inv, a, closest, rng, stk_ref, 0u, lane, t)
-                                                     : sphere_t(mk(q0.x, q0.y, q0.z), q1.x, r, a, closest, t);
+                                                     : sphere_t(mk(q0.x, q0.y, q0.z), q0.w, r, a, closest, t);
                     if (got) {
                         closest = t; best_take(best, t, ref);
                     }
@@ -1395,6 +1393,7 @@ RTR_DEV bool claim_ticket(KParams p, uint32_t lane, uint32_t &id) {
 
 // calculate_pixel's per-sample head (render.rs:80-90) and Camera::get_ray (camera.rs:19-24): the launch's wave-uniform
 // constants, and the start of sample `si` of the pixel whose stream hash is `hp`.
+constexpr uint32_t kSampleKeyStep = 0x9E3779B9u; // odd: sample index -> key is one-to-one modulo 2^32
 struct Primary {
     V3 o, h, v, llc;
     SharedDiv div_w, div_h; // (x + xi) / (W - 1), (y + xi') / (H - 1): wave-uniform denominators in [1, 2^31] (else the plain
@@ -1407,7 +1406,11 @@ struct Primary {
         uv_fast = div_w.ok && div_h.ok;
     }
     RTR_DEV void start(uint32_t hp, uint32_t si, float fx, float fy, Rng &rng, Ray &ray) const {
-        rng.state = hash32(hp + si * 0x9E3779B9u);
+        start_key(hp + si * kSampleKeyStep, fx, fy, rng, ray);
+    }
+    // ... given the sample's stream key hp + si * kSampleKeyStep (k_render steps the key from sample to sample)
+    RTR_DEV void start_key(uint32_t key, float fx, float fy, Rng &rng, Ray &ray) const {
+        rng.state = hash32(key);
         float uu = fx + rng_unit_inclusive(rng); // render.rs:88-89
         float vv = fy + rng_unit_inclusive(rng);
         if (uv_fast) {
@@ -1595,16 +1598,18 @@ __global__ __launch_bounds__(64, WORLD == WORLD_LINEAR_SPHERES ? (NS >= 1u && NS
         rng.inc = tk.inc;
         rng.state = 0u;
         V3 acc = tk.acc;
-        uint32_t s = tk.s_first, depth = 0;
+        // the lane's sample counter lives as the sample's stream key (one add per sample instead of a quarter-rate multiply)
+        uint32_t key = hp + tk.s_first * kSampleKeyStep, depth = 0;
+        const uint32_t key_end = hp + spp * kSampleKeyStep;
         Ray ray;
         ray.o = cam.o; ray.d = cam.o;
-        if (s < spp) { cam.start(hp, s, fx, fy, rng, ray); chain.reset(); }
+        if (key != key_end) { cam.start_key(key, fx, fy, rng, ray); chain.reset(); }
 #ifdef RTR_X_LIFE
         __builtin_amdgcn_s_waitcnt(0);
         life_t1 = __builtin_amdgcn_s_memrealtime();
 #endif
 
-        while (s < spp) {
+        while (key != key_end) {
             RTR_STAMP(4)
             RTR_LS(1, true) RTR_LS1(0)
             // ---- trace_ray body (render.rs:32-59): one segment ----
@@ -1619,8 +1624,8 @@ __global__ __launch_bounds__(64, WORLD == WORLD_LINEAR_SPHERES ? (NS >= 1u && NS
             if (done) {
                 RTR_LS1(22)
                 acc = add(acc, sample_radiance(p, lds_mats, chain, term)); // render.rs:99
-                s++;
-                if (s < spp) { cam.start(hp, s, fx, fy, rng, ray); depth = 0; chain.reset(); }
+                key += kSampleKeyStep;
+                if (key != key_end) { cam.start_key(key, fx, fy, rng, ray); depth = 0; chain.reset(); }
             }
             RTR_STAMP(3)
         }

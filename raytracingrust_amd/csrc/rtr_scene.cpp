@@ -296,8 +296,11 @@ struct Flattener {
     Emitted emit_sphere(uint32_t object, const rtr_sphere &s) {
         uint32_t L = obj_leaf_base[object];
         DevLeafHot hot{};
-        hot.f[0] = s.center[0]; hot.f[1] = s.center[1]; hot.f[2] = s.center[2]; hot.f[3] = s.radius;
-        hot.f[4] = s.radius * s.radius; // objects.rs:27 `self.radius * self.radius`
+        // centre and r^2 -- all Sphere::hit reads -- in the first 16 bytes: a leaf test is ONE load instruction (the leaf block of
+        // a trip runs with few lanes, where a gather costs per instruction: DESIGN.md section 5.2); the radius is read once, by the winner
+        hot.f[0] = s.center[0]; hot.f[1] = s.center[1]; hot.f[2] = s.center[2];
+        hot.f[3] = s.radius * s.radius; // objects.rs:27 `self.radius * self.radius`
+        hot.f[4] = s.radius;
         DevLeafCold cold{};
         cold.material = s.material; cold.object = object; cold.handle = 0;
         out.leaf_hot[L] = hot;
