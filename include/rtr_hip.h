@@ -270,7 +270,12 @@ int rtr_abi_version(void);
 /*   "sample_chunks" = "auto" (default) | "1" .. "4096" (applied at the next render): pieces every pixel's sample range
  *                 is cut into inside one launch.  Each piece continues the running sums of the one before it in the
  *                 same order, so the frame is bit-identical for every value; more pieces shorten the tail of a launch
- *                 that has few tiles per resident wave (1080p: -9 % with 4) and cost a workgroup prologue each.
+ *                 that has few tiles per resident wave and cost a workgroup prologue and a ragged end each.  "auto": the
+ *                 sphere world takes three pieces in the proportions 24:7:1 from 96 samples on and two (7:1) from 24
+ *                 (1080p, 256 samples: 13.0 ms against 16.6 in one piece); an explicit count is cut with linearly falling
+ *                 lengths.  The hand-over between pieces is made of device-scope atomic loads and stores only.
+ *   "debug_chunk_lengths" = "a:b:..." (1 .. 8 positive integers): measuring aid, the pieces' relative lengths (sets the
+ *                 count too); "debug_chunk_taper" = "auto" | 0 .. 7: how steeply an explicit count's lengths fall.
  *   "chunk_timeout_ms" = "10000" (default) | milliseconds: how long a piece waits for the piece before it.  HIP does
  *                 not promise dispatch order, so the wait is bounded; a piece that gives up sets the context's device
  *                 fault word and the next synchronising call (rtr_render*, rtr_get_stats, rtr_kernel_times_ms,
