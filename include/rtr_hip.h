@@ -271,8 +271,8 @@ int rtr_abi_version(void);
  *                 is cut into inside one launch.  Each piece continues the running sums of the one before it in the
  *                 same order, so the frame is bit-identical for every value; more pieces shorten the tail of a launch
  *                 that has few tiles per resident wave and cost a workgroup prologue and a ragged end each.  "auto": the
- *                 sphere world takes three pieces in the proportions 24:7:1 from 96 samples on and two (7:1) from 24
- *                 (1080p, 256 samples: 13.0 ms against 16.6 in one piece); an explicit count is cut with linearly falling
+ *                 sphere world takes three pieces in the proportions 24:7:1 from 96 samples on and two (7:1) from 28
+ *                 (1080p, 256 samples: 13.0 ms against 14.7 in one piece); an explicit count is cut with linearly falling
  *                 lengths.  The hand-over between pieces is made of device-scope atomic loads and stores only.
  *   "debug_chunk_lengths" = "a:b:..." (1 .. 8 positive integers): measuring aid, the pieces' relative lengths (sets the
  *                 count too); "debug_chunk_taper" = "auto" | 0 .. 7: how steeply an explicit count's lengths fall.

@@ -339,8 +339,8 @@ int launch_frame(rtr_context *ctx, const rtr_camera *camera, const rtr_settings 
     // the hand-over made of device-scope atomics): few pieces of steeply falling length -- a workgroup's ragged end costs
     // about as much for a long piece as for a short one, and only the LAST pieces are what the chip drains on.  Headline
     // frame, proportions a:b:c of the samples: 24:7:1 13.01 ms, 28:3:1 13.00, 20:10:2 13.06, 15:10:6:1 (linear taper 7) 13.11,
-    // 16:8:4:2:1 13.32, 15:1 13.74; 128 samples 24:7:1 6.65 / 7:1 6.73 / one piece 7.41; 64 samples 7:1 3.49 / 24:7:1 3.66 / one
-    // piece 3.80; 32 samples 7:1 1.87 / one piece 2.02 (what a rank of the 2-, 4- and 8-GPU sample split renders).  Tree worlds
+    // 16:8:4:2:1 13.32, 15:1 13.74, one piece 14.72; 128 samples 24:7:1 6.65 / 7:1 6.73 / one piece 7.41; 64 samples 7:1 3.49 / 24:7:1 3.66 / one
+    // piece 3.80; 32 samples 7:1 1.87 / one piece 2.02; 24 samples 1.69 / 1.68; 16 samples 1.34 / 1.17 (what a rank of the 2-, 4- and 8-GPU sample split renders).  Tree worlds
     // (k_render_bvh): up to 4 equal pieces of at least 16 samples.
     p.tiles_launch = grid > 0u ? grid : 1u;
     p.chunks = 1u;
@@ -355,7 +355,7 @@ int launch_frame(rtr_context *ctx, const rtr_camera *camera, const rtr_settings 
             want = std::min(std::max(1u, 80u * resident / grid), std::max(1u, sample_count / 4u));
         } else {
             const uint32_t resident = std::max(1u, rtr::render_resident_waves(p, lds_bytes));
-            const uint32_t by_length = p.world == rtr::WORLD_LINEAR_SPHERES ? (sample_count >= 96u ? 3u : sample_count >= 24u ? 2u : 1u)
+            const uint32_t by_length = p.world == rtr::WORLD_LINEAR_SPHERES ? (sample_count >= 96u ? 3u : sample_count >= 28u ? 2u : 1u)
                                                                             : std::min(4u, sample_count / 16u);
             if (grid >= 2u * resident) want = std::min(24u * resident / grid, by_length);
             if (p.world == rtr::WORLD_LINEAR_SPHERES) auto_profile = want == 3u ? 1 : want == 2u ? 2 : 0;
