@@ -45,13 +45,13 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
 VALU_PEAK_WAVE_INSTS_PER_S = 256 * 4 * 2.4e9 / 2.0
 PROFILE_ROUND = "r03"
 # The tree kernels' bound (round 3): the vector L1's gather rate.  Every node step gathers a per-lane 56-byte record (three
-# 16-byte loads + one 8-byte load), every leaf test 36 (triangle) or 20 (sphere) bytes, and a wave's gather of per-lane
+# 16-byte loads + one 8-byte load), every leaf test 36 (triangle) or 16 (sphere: centre + r^2) bytes, and a wave's gather of per-lane
 # 64-byte-aligned records is served at 18-21 B per clock and CU whether the table sits in L1 or L2 -- measured with
 # scripts/ubench/gather.hip (profiles/r02/evidence/ubench_gather.txt: 56 B per lane, 16 KB table 12 795 GB/s, 1 MB table
 # 11 965 GB/s chip-wide).  Peak = the mean of the two; achieved = bytes the walk gathered (device-counted node steps and leaf
 # tests of one frame, option "traversal_counters") over the integrate kernel's time.
 L1_GATHER_PEAK_GBS = 12380.0
-NODE_GATHER_BYTES, TRIANGLE_GATHER_BYTES, SPHERE_GATHER_BYTES = 56.0, 36.0, 20.0
+NODE_GATHER_BYTES, TRIANGLE_GATHER_BYTES, SPHERE_GATHER_BYTES = 56.0, 36.0, 16.0
 
 
 def parse_args(argv=None):

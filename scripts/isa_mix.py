@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Static instruction mix of an integrate kernel's loops, from the ISA hipcc emits for gfx950 with the product's flags
 (no GPU needed).  usage: python scripts/isa_mix.py [mangled-kernel-name-prefix]   (default: the headline kernel
-k_render<WORLD_LINEAR_SPHERES, 5>).  Prints, for the kernel's largest loops, the instruction count by class: spill traffic
+k_render<WORLD_LINEAR_SPHERES, 5, 0, false, PLAIN = true>).  Prints, for the kernel's largest loops, the instruction count by class: spill traffic
 (v_readlane / v_writelane), compares and selects (the pairs gfx950 separates by wait states), transcendental and 32-bit
 integer multiplies (quarter rate), scalar ALU by kind (exec-mask handling, branches, s_nop wait states), LDS and memory."""
 import collections
@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from raytracingrust_amd import build as B  # noqa: E402
 
-name = sys.argv[1] if len(sys.argv) > 1 else "_ZN3rtr8k_renderILj0ELj5ELj0ELb0EEEvNS_12RenderParamsE"
+name = sys.argv[1] if len(sys.argv) > 1 else "_ZN3rtr8k_renderILj0ELj5ELj0ELb0ELb1EEEvNS_12RenderParamsE"
 flags = [f for f in B.FLAGS if f not in ("-shared", "-fPIC")]
 with tempfile.TemporaryDirectory() as tmp:
     asm = os.path.join(tmp, "k.s")
