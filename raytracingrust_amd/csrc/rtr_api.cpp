@@ -321,18 +321,18 @@ int launch_frame(rtr_context *ctx, const rtr_camera *camera, const rtr_settings 
         // ... and its form in which lanes share samples at the ends of tickets (k_render_share; option "lane_sharing"): the
         // attenuation chain is a register of 3-bit sphere slots there, and the chain's LDS holds the pool of parked samples --
         // as many entries as fit the 5120 bytes a wave may take at 8 waves per SIMD
-        p.lane_sharing = (plain && ctx->lane_sharing && p.sphere_regs <= 5u && p.max_depth <= 10u) ? 1u : 0u;
+        p.lane_sharing = (plain && ctx->lane_sharing && p.sphere_regs <= 5u && p.max_depth <= 10u && width <= 65536u && height <= 65536u) ? 1u : 0u;
         p.share_pool = 0u;
         if (p.lane_sharing) {
             const uint32_t tables = (2u * p.sphere_regs + p.lds_materials) * 32u;
-            p.share_pool = tables + 20u * 16u <= 5120u ? std::min(240u, (5120u - tables) / 20u) : 16u;
+            p.share_pool = tables + 16u * 16u <= 5120u ? (5120u - tables) / 16u : 16u;
             if (ctx->share_pool >= 0) p.share_pool = std::min<uint32_t>((uint32_t)ctx->share_pool, 4096u);
             p.chain_lds = 0u;
         }
     }
     p.stack_packed = (p.sample_parallel && !streaming && !ctx->stack_wide && fs.nodes.size() <= 65536u && fs.leaf_hot.size() <= 65536u) ? 1u : 0u; // (the samples kernel has both forms)
     uint32_t lds_bytes = p.chain_lds * 64u * 4u + p.stack_cap * 64u * rtr::stack_entry_bytes(p) + (2u * p.sphere_regs + p.lds_materials) * 32u; // spheres, their materials' copies, the material table
-    if (p.lane_sharing) lds_bytes += p.share_pool * 20u;
+    if (p.lane_sharing) lds_bytes += p.share_pool * 16u;
 #ifdef RTR_X_SHARE_LDSCHAIN
     if (p.lane_sharing) lds_bytes += 3u * p.max_depth * 256u;
 #endif

@@ -1687,7 +1687,7 @@ __global__ __launch_bounds__(64, WORLD == WORLD_LINEAR_SPHERES ? (NS >= 1u && NS
 // added, adds the parked ones in index order (they form a list through the pool: the most recently given sample has the
 // smallest index and is the list's head).  Every sample is computed by exactly the operations k_render spends on it and
 // every pixel sees exactly the additions of the unshared loop: bit-identical frames.
-// Pool entry (5 words): while the sample is being traced [key, fx, fy, rng.inc, next]; afterwards [r, g, b, -, next | READY].
+// Pool entry (4 words): while the sample is being traced [key, x | y << 16, rng.inc, next]; afterwards [r, g, b, next | READY].
 // A sharing round pairs the j-th free lane with the j-th donor by their ranks in the two lane masks (no search, one LDS
 // round trip); donors are the lanes holding at least half of the wave's largest unstarted count.
 constexpr uint32_t kJobNone = 0xFFFFFFFFu, kJobOwn = 0xFFFFFFFEu, kShareNone = 0x7FFFFFFFu, kShareReady = 0x80000000u;
@@ -1701,7 +1701,7 @@ __global__ __launch_bounds__(64, 8) void k_render_share(const RenderParams p) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const uint32_t lane = threadIdx.x;
     uint32_t *pool = lds;
-    uint32_t *lds_spheres = pool + p.share_pool * 5u;
+    uint32_t *lds_spheres = pool + p.share_pool * 4u;
     uint32_t *lds_mat_base = lds_spheres + NS * 8u;
     const uint32_t *lds_mats = lds_mat_base;
     SphereRegs<NS> sr;
@@ -1752,51 +1752,52 @@ __global__ __launch_bounds__(64, 8) void k_render_share(const RenderParams p) {
         const uint32_t pool_size = p.share_pool;
         Ray ray;
         ray.o = cam.o; ray.d = cam.o;
+        if (left != 0u) { // the first own sample (render.rs:80-90); from here on a lane without a job has none left to start
+            cam.start_key(key, fx, fy, rng, ray);
+            key += kSampleKeyStep; left--; chain.reset(); job = kJobOwn;
+        }
         for (;;) {
-            if (job == kJobNone) {
-                if (left != 0u) { // the next own sample (render.rs:80-90)
-                    cam.start_key(key, fx, fy, rng, ray);
-                    key += kSampleKeyStep; left--; depth = 0u; chain.reset(); job = kJobOwn;
-                } else if (head != kShareNone) { // own samples added: now the parked ones, in index order
-                    const uint32_t *e = pool + head * 5u;
-                    const uint32_t w = e[4];
+            const uint64_t free_m = wave_mask(job == kJobNone);
+            if (free_m != 0ull) { // (a scalar branch: trips in which every lane has a sample under way skip all of this)
+                if (job == kJobNone && head != kShareNone) { // own samples added: now the parked ones, in index order
+                    const uint32_t *e = pool + head * 4u;
+                    const uint32_t w = e[3];
                     if (w & kShareReady) {
                         acc = add(acc, mk(__uint_as_float(e[0]), __uint_as_float(e[1]), __uint_as_float(e[2])));
                         head = w & kShareNone;
                     }
                 }
-            }
-            const uint64_t free_m = wave_mask(job == kJobNone && left == 0u);
-            if (free_m != 0ull && pool_next < pool_size) { // a sharing round
-                const uint32_t most = wave_max_u32(left);
-                const uint32_t thr = most > 1u ? most >> 1 : 1u;
-                const uint64_t donor_m = wave_mask(left >= thr && most != 0u);
-                uint32_t n = (uint32_t)__popcll(free_m), nd = (uint32_t)__popcll(donor_m);
-                n = n < nd ? n : nd;
-                n = n < pool_size - pool_next ? n : pool_size - pool_next;
-                if (n != 0u) {
-                    const uint32_t rd = __builtin_amdgcn_mbcnt_hi((uint32_t)(donor_m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)donor_m, 0u));
-                    if (lane_of(donor_m) && rd < n) { // give the LAST unstarted sample away
-                        left--;
-                        uint32_t *e = pool + (pool_next + rd) * 5u;
-                        e[0] = key + left * kSampleKeyStep; e[1] = __float_as_uint(fx); e[2] = __float_as_uint(fy); e[3] = rng.inc;
-                        e[4] = head;
-                        head = pool_next + rd;
+                if (pool_next < pool_size) { // a sharing round
+                    const uint32_t most = wave_max_u32(left);
+                    const uint32_t thr = most > 3u ? most >> 1 : 2u;
+                    const uint64_t donor_m = wave_mask(left >= thr);
+                    uint32_t n = (uint32_t)__popcll(free_m), nd = (uint32_t)__popcll(donor_m);
+                    n = n < nd ? n : nd;
+                    n = n < pool_size - pool_next ? n : pool_size - pool_next;
+                    if (n != 0u) {
+                        const uint32_t rd = __builtin_amdgcn_mbcnt_hi((uint32_t)(donor_m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)donor_m, 0u));
+                        if (lane_of(donor_m) && rd < n) { // give the LAST unstarted sample away
+                            left--;
+                            uint32_t *e = pool + (pool_next + rd) * 4u;
+                            e[0] = key + left * kSampleKeyStep; e[1] = (uint32_t)fx | ((uint32_t)fy << 16); e[2] = rng.inc; // (x, y < 65536: rtr_api.cpp)
+                            e[3] = head;
+                            head = pool_next + rd;
+                        }
+                        __builtin_amdgcn_s_waitcnt(0xC07F); // lgkmcnt(0): the donors' entries are in LDS
+                        __builtin_amdgcn_wave_barrier();
+                        const uint32_t rf = __builtin_amdgcn_mbcnt_hi((uint32_t)(free_m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)free_m, 0u));
+                        if (lane_of(free_m) && rf < n) { // take it: the donor pixel's coordinates and stream
+                            const uint32_t *e = pool + (pool_next + rf) * 4u;
+                            const uint32_t skey = e[0], xy = e[1];
+                            fx = (float)(xy & 0xFFFFu); fy = (float)(xy >> 16); rng.inc = e[2];
+                            cam.start_key(skey, fx, fy, rng, ray);
+                            depth = 0u; chain.reset(); job = pool_next + rf;
+                        }
+                        pool_next += n;
                     }
-                    __builtin_amdgcn_s_waitcnt(0xC07F); // lgkmcnt(0): the donors' entries are in LDS
-                    __builtin_amdgcn_wave_barrier();
-                    const uint32_t rf = __builtin_amdgcn_mbcnt_hi((uint32_t)(free_m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)free_m, 0u));
-                    if (lane_of(free_m) && rf < n) { // take it: the donor pixel's coordinates and stream
-                        const uint32_t *e = pool + (pool_next + rf) * 5u;
-                        const uint32_t skey = e[0];
-                        fx = __uint_as_float(e[1]); fy = __uint_as_float(e[2]); rng.inc = e[3];
-                        cam.start_key(skey, fx, fy, rng, ray);
-                        depth = 0u; chain.reset(); job = pool_next + rf;
-                    }
-                    pool_next += n;
                 }
+                if (wave_mask(job != kJobNone || head != kShareNone) == 0ull) break;
             }
-            if (wave_mask(job != kJobNone || left != 0u || head != kShareNone) == 0ull) break;
             if (job != kJobNone) {
                 // ---- trace_ray body (render.rs:32-59): one segment ----
                 Hit h;
@@ -1815,9 +1816,9 @@ __global__ __launch_bounds__(64, 8) void k_render_share(const RenderParams p) {
                             job = kJobNone;
                         }
                     } else { // park it for the pixel's lane
-                        uint32_t *e = pool + job * 5u;
+                        uint32_t *e = pool + job * 4u;
                         e[0] = __float_as_uint(rad.x); e[1] = __float_as_uint(rad.y); e[2] = __float_as_uint(rad.z);
-                        e[4] |= kShareReady; // (after the three words: LDS operations of a wave complete in order)
+                        e[3] |= kShareReady; // (after the three words: LDS operations of a wave complete in order)
                         job = kJobNone;
                     }
                 }
