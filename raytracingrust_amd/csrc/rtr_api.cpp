@@ -84,8 +84,6 @@ struct rtr_context {
     void *d_wf = nullptr;  // streaming wavefront: the path records of one batch (ray, hit, state, chain, stage)
     size_t wf_cap = 0;
     int sample_chunks = 0; // option "sample_chunks": 0 auto, else the number of pieces
-    int share_pool = -1;      // option "debug_share_pool": -1 auto, else the pool's entries (0: k_render_share never shares)
-    bool lane_sharing = false; // option "lane_sharing" (experiment: off unless asked for): the plain sphere world's kernel in which idle lanes trace other pixels' samples
     int chunk_taper = -1;  // option "debug_chunk_taper": -1 auto, else 0..7 (chunk_boundary in rtr_kernels.hip)
     std::vector<uint32_t> chunk_lengths; // option "debug_chunk_lengths": proportions of the chunks ("15:10:6:1"); sets sample_chunks too
     double chunk_timeout_s = 10.0; // option "chunk_timeout_ms": bound of a sample chunk's wait for its predecessor
@@ -318,24 +316,9 @@ int launch_frame(rtr_context *ctx, const rtr_camera *camera, const rtr_settings 
         bool plain = p.sphere_regs >= 1u && p.mode == 0u && p.bg_kind == 0u && p.chain_bits != 0xFFFFFFFFu && p.lds_materials > 0u;
         for (const rtr::DevMaterial &m : fs.materials) plain = plain && m.kind != 4u && m.kind != 5u;
         p.plain_sphere_world = plain ? 1u : 0u;
-        // ... and its form in which lanes share samples at the ends of tickets (k_render_share; option "lane_sharing"): the
-        // attenuation chain is a register of 3-bit sphere slots there, and the chain's LDS holds the pool of parked samples --
-        // as many entries as fit the 5120 bytes a wave may take at 8 waves per SIMD
-        p.lane_sharing = (plain && ctx->lane_sharing && p.sphere_regs <= 5u && p.max_depth <= 10u && width <= 65536u && height <= 65536u) ? 1u : 0u;
-        p.share_pool = 0u;
-        if (p.lane_sharing) {
-            const uint32_t tables = (2u * p.sphere_regs + p.lds_materials) * 32u;
-            p.share_pool = tables + 16u * 16u <= 5120u ? (5120u - tables) / 16u : 16u;
-            if (ctx->share_pool >= 0) p.share_pool = std::min<uint32_t>((uint32_t)ctx->share_pool, 4096u);
-            p.chain_lds = 0u;
-        }
     }
     p.stack_packed = (p.sample_parallel && !streaming && !ctx->stack_wide && fs.nodes.size() <= 65536u && fs.leaf_hot.size() <= 65536u) ? 1u : 0u; // (the samples kernel has both forms)
     uint32_t lds_bytes = p.chain_lds * 64u * 4u + p.stack_cap * 64u * rtr::stack_entry_bytes(p) + (2u * p.sphere_regs + p.lds_materials) * 32u; // spheres, their materials' copies, the material table
-    if (p.lane_sharing) lds_bytes += p.share_pool * 16u;
-#ifdef RTR_X_SHARE_LDSCHAIN
-    if (p.lane_sharing) lds_bytes += 3u * p.max_depth * 256u;
-#endif
     lds_bytes += ctx->debug_lds_pad;
     if (lds_bytes > 160u * 1024u) return fail(ctx, RTR_ERR_UNSUPPORTED, "max_ray_depth + tree height exceed one CU's LDS");
     ctx->last_lds = lds_bytes;
@@ -792,7 +775,7 @@ int multi_frame(rtr_context *ctx, const rtr_camera *camera, const rtr_settings *
     }
     for (uint32_t r = 0; r < n; r++) {
         rtr_context *rk = ctx->ranks[r];
-        rk->tree_kernel = ctx->tree_kernel; rk->sample_chunks = ctx->sample_chunks; rk->chunk_taper = ctx->chunk_taper; rk->lane_sharing = ctx->lane_sharing; rk->share_pool = ctx->share_pool; rk->chunk_lengths = ctx->chunk_lengths; rk->block_samples = ctx->block_samples;
+        rk->tree_kernel = ctx->tree_kernel; rk->sample_chunks = ctx->sample_chunks; rk->chunk_taper = ctx->chunk_taper; rk->chunk_lengths = ctx->chunk_lengths; rk->block_samples = ctx->block_samples;
         rk->samples_batch = ctx->samples_batch; rk->stack_wide = ctx->stack_wide; rk->sky_bilinear = ctx->sky_bilinear;
         rk->chunk_timeout_s = ctx->chunk_timeout_s; rk->wf_flush = ctx->wf_flush; rk->debug_fault = ctx->debug_fault;
         rk->traversal_counters = ctx->traversal_counters;
@@ -1094,19 +1077,6 @@ int rtr_set_option(rtr_context *ctx, const char *name, const char *value) {
         const unsigned long k = std::strtoul(v.c_str(), &end, 10);
         if (v.empty() || *end != '\0' || k < 1ul || k > 4096ul) return fail(ctx, RTR_ERR_INVALID_ARGUMENT, "sample_chunks must be \"auto\" or an integer in [1, 4096]");
         ctx->sample_chunks = (int)k;
-        return RTR_OK;
-    }
-    if (n == "debug_share_pool") { // measuring aid
-        char *end = nullptr;
-        const long k = std::strtol(v.c_str(), &end, 10);
-        if (v.empty() || *end != '\0' || k < -1 || k > 4096) return fail(ctx, RTR_ERR_INVALID_ARGUMENT, "debug_share_pool must be -1 .. 4096");
-        ctx->share_pool = (int)k;
-        return RTR_OK;
-    }
-    if (n == "lane_sharing") { // takes effect at the next render
-        if (v == "on" || v == "auto") ctx->lane_sharing = true;
-        else if (v == "off") ctx->lane_sharing = false;
-        else return fail(ctx, RTR_ERR_INVALID_ARGUMENT, "lane_sharing must be \"auto\", \"on\" or \"off\"");
         return RTR_OK;
     }
     if (n == "debug_chunk_lengths") { // measuring aid: relative chunk lengths, e.g. "24:7:1" (any values give the same frame)

@@ -101,8 +101,6 @@ struct RenderParams {
     uint32_t plain_sphere_world; // ... in RenderMode::Full over a UniformBackground, no MixMaterial / Isotropic, attenuations in the chain:
                             // the instantiation without those wave-uniform tests (shade_segment<PLAIN>)
     uint32_t lds_materials; // number of material records staged in LDS (0 = read from HBM/L1)
-    uint32_t lane_sharing;  // plain sphere world, <= 5 spheres, max_ray_depth <= 10: k_render_share (lanes with nothing left trace other
-    uint32_t share_pool;    // pixels' last samples); entries of its wave-private pool of parked samples in LDS (4 words each)
     uint32_t has_meshes;    // the scene holds triangles: tree kernels instantiated with the unconditional slab tests
     uint32_t sample_parallel; // WORLD_BVH: k_render_bvh_sp + k_sum_samples
     uint32_t resumable_walk; // WORLD_BVH: k_render_bvh (per-lane walk state machine) instead of k_render

@@ -1132,20 +1132,6 @@ struct PackChain { // the tree worlds'
         return id;
     }
 };
-struct SlotChain { // k_render_share's: the bounce's sphere SLOT, three bits per entry in one register (up to 10 bounces); the
-    static constexpr bool kStoresRgb = false; // attenuation is read back from the slot's material copy in LDS (slot_mats)
-    static constexpr bool kPairedReplay = true;
-    const uint32_t *tbl;
-    uint32_t n, packed; // n counts BITS (three per entry): the shifts need no multiply
-    RTR_DEV void init(const uint32_t *slot_mats) { tbl = slot_mats; n = 0u; packed = 0u; }
-    RTR_DEV void reset() { n = 0u; packed = 0u; }
-    RTR_DEV void push(uint32_t slot, V3) { packed |= slot << n; n += 3u; }
-    RTR_DEV V3 pop_rgb(const RenderParams &, const uint32_t *) {
-        n -= 3u;
-        const float4 m = *reinterpret_cast<const float4 *>(tbl + __builtin_amdgcn_ubfe(packed, n, 3u) * 8u); // one 16-byte LDS read
-        return mk(m.x, m.y, m.z);
-    }
-};
 struct GlobalChain {
     static constexpr bool kStoresRgb = false;
     uint32_t *base;
@@ -1168,8 +1154,6 @@ RTR_DEV V3 clamp_radiance(const RenderParams &p, V3 term) {
     if (term.z > hi) term.z = hi;
     return term;
 }
-template <class C, class = void> struct chain_pairs : std::false_type {};
-template <class C> struct chain_pairs<C, std::enable_if_t<C::kPairedReplay>> : std::true_type {};
 // attenuation * (attenuation * (... * terminal)) (render.rs:52), then the clamp: the radiance one finished sample adds
 // to its pixel
 template <class Chain>
@@ -1177,11 +1161,6 @@ RTR_DEV V3 sample_radiance(const RenderParams &p, const uint32_t *lds_mats, Chai
     if constexpr (Chain::kStoresRgb) {
         // two entries per round: their reads are independent, so the replay costs one LDS round trip per PAIR of bounces
         while (chain.n >= 2u) {
-            const V3 inner = chain.pop_rgb(p, lds_mats), outer = chain.pop_rgb(p, lds_mats);
-            term = mul(outer, mul(inner, term));
-        }
-    } else if constexpr (chain_pairs<Chain>::value) {
-        while (chain.n >= 6u) { // (SlotChain counts bits: two entries)
             const V3 inner = chain.pop_rgb(p, lds_mats), outer = chain.pop_rgb(p, lds_mats);
             term = mul(outer, mul(inner, term));
         }
@@ -1309,7 +1288,7 @@ RTR_DEV bool shade_segment(const RenderParams &p, bool was_hit, const Hit &h, Ra
         }
         if (scattered) {
             if (mid != 0xFFFFFFFEu) {
-                chain.push(PLAIN ? h.slot : mid, rgb); // (PLAIN: LdsChain keeps the colour itself, SlotChain the sphere's slot)
+                chain.push(mid, rgb);
             }
             ray.o = h.point;
             ray.d = ndir;
@@ -1674,158 +1653,6 @@ __global__ __launch_bounds__(64, WORLD == WORLD_LINEAR_SPHERES ? (NS >= 1u && NS
     if (lane < 32u && p.spp > 1u) // scripts/lanestat.py makes 32 one-sample launches first, so slots counter-1..-32 exist
         atomicAdd(p.counter - 1 - lane, (unsigned long long)rtr_lsc[lane]);
 #endif
-    count_segments(nseg, lane);
-}
-
-// ---- Sphere world, plain case, lanes SHARE samples at the end of a ticket ---------------------------------------------
-// In k_render a lane is tied to its pixel: it traces the pixel's samples of the ticket one after the other, and the wave
-// leaves the ticket when its slowest lane has finished -- 58 of 64 lanes are alive in an average trip of the headline frame
-// (scripts/lanestat.py), the rest wait at the ragged end.  Only the ADDITION of a pixel's samples has to happen in index
-// order (render.rs:99); a sample's radiance is a function of (pixel, sample index) alone.  Here a lane with nothing left
-// to trace takes the LAST unstarted sample of a lane that still has several (a "donor"), traces it under the donor
-// pixel's stream key, and parks the clamped radiance in a wave-private pool in LDS; the donor, once its own samples are
-// added, adds the parked ones in index order (they form a list through the pool: the most recently given sample has the
-// smallest index and is the list's head).  Every sample is computed by exactly the operations k_render spends on it and
-// every pixel sees exactly the additions of the unshared loop: bit-identical frames.
-// Pool entry (4 words): while the sample is being traced [key, x | y << 16, rng.inc, next]; afterwards [r, g, b, next | READY].
-// A sharing round pairs the j-th free lane with the j-th donor by their ranks in the two lane masks (no search, one LDS
-// round trip); donors are the lanes holding at least half of the wave's largest unstarted count.
-constexpr uint32_t kJobNone = 0xFFFFFFFFu, kJobOwn = 0xFFFFFFFEu, kShareNone = 0x7FFFFFFFu, kShareReady = 0x80000000u;
-RTR_DEV uint32_t wave_max_u32(uint32_t v) {
-    for (int off = 32; off > 0; off >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)v, off, 64); v = o > v ? o : v; }
-    return v;
-}
-template <uint32_t NS>
-__attribute__((amdgpu_num_sgpr(96)))
-__global__ __launch_bounds__(64, 8) void k_render_share(const RenderParams p) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-    const uint32_t lane = threadIdx.x;
-    uint32_t *pool = lds;
-    uint32_t *lds_spheres = pool + p.share_pool * 4u;
-    uint32_t *lds_mat_base = lds_spheres + NS * 8u;
-    const uint32_t *lds_mats = lds_mat_base;
-    SphereRegs<NS> sr;
-#pragma unroll
-    for (uint32_t i = 0; i < NS; i++) {
-        const DevLinSphere &sp = p.lin_spheres[i]; // uniform -> scalar loads, kept in SGPRs
-        sr.cx[i] = sp.center[0]; sr.cy[i] = sp.center[1]; sr.cz[i] = sp.center[2]; sr.r2[i] = sp.radius2;
-    }
-    for (uint32_t i = lane; i < NS * 8u; i += 64u) lds_spheres[i] = reinterpret_cast<const uint32_t *>(p.lin_spheres)[i];
-    __builtin_amdgcn_s_waitcnt(0);
-    __builtin_amdgcn_wave_barrier();
-    if (lane < NS) { // the two pad words of the LDS copy: the radius' prepared reciprocal and its validity (as in k_render)
-        const SharedDiv sd = shared_div_prepare(__uint_as_float(lds_spheres[lane * 8u + 3u]));
-        lds_spheres[lane * 8u + 6u] = __float_as_uint(sd.r1);
-        lds_spheres[lane * 8u + 7u] = sd.ok ? 1u : 0u;
-    }
-    stage_materials(p, lds_mat_base, lane);
-    uint32_t *slot_mats = lds_mat_base + p.lds_materials * 8u;
-    for (uint32_t i = lane; i < NS * 8u; i += 64u)
-        slot_mats[i] = reinterpret_cast<const uint32_t *>(p.materials)[p.lin_spheres[i >> 3].material * 8u + (i & 7u)];
-    __builtin_amdgcn_s_waitcnt(0);
-    __builtin_amdgcn_wave_barrier();
-
-#ifdef RTR_X_SHARE_LDSCHAIN
-    LdsChain<false> chain;
-    chain.init(lds_mat_base + p.lds_materials * 8u + NS * 8u, lane, 0u);
-#else
-    SlotChain chain;
-    chain.init(slot_mats);
-#endif
-    Primary cam;
-    cam.init(p);
-    uint32_t nseg = 0;
-    uint32_t ticket;
-    if (claim_ticket(kernarg_params(), lane, ticket)) {
-        const TicketLane tk = ticket_begin(ticket, lane);
-        const uint32_t pixel = tk.pixel;
-        float fx = tk.fx, fy = tk.fy;
-        Rng rng;
-        rng.inc = tk.inc;
-        rng.state = 0u;
-        V3 acc = tk.acc;
-        uint32_t key = tk.hp + tk.s_first * kSampleKeyStep; // the next own sample to start
-        uint32_t left = tk.s_end - tk.s_first;              // own samples not started yet
-        uint32_t job = kJobNone;                            // kJobOwn, or the pool entry a sample is traced for
-        uint32_t head = kShareNone;                         // the given-away samples still to be added, smallest index first
-        uint32_t pool_next = 0u, depth = 0u;                // (pool_next: wave-uniform)
-        const uint32_t pool_size = p.share_pool;
-        Ray ray;
-        ray.o = cam.o; ray.d = cam.o;
-        if (left != 0u) { // the first own sample (render.rs:80-90); from here on a lane without a job has none left to start
-            cam.start_key(key, fx, fy, rng, ray);
-            key += kSampleKeyStep; left--; chain.reset(); job = kJobOwn;
-        }
-        for (;;) {
-            const uint64_t free_m = wave_mask(job == kJobNone);
-            if (free_m != 0ull) { // (a scalar branch: trips in which every lane has a sample under way skip all of this)
-                if (job == kJobNone && head != kShareNone) { // own samples added: now the parked ones, in index order
-                    const uint32_t *e = pool + head * 4u;
-                    const uint32_t w = e[3];
-                    if (w & kShareReady) {
-                        acc = add(acc, mk(__uint_as_float(e[0]), __uint_as_float(e[1]), __uint_as_float(e[2])));
-                        head = w & kShareNone;
-                    }
-                }
-                if (pool_next < pool_size) { // a sharing round
-                    const uint32_t most = wave_max_u32(left);
-                    const uint32_t thr = most > 3u ? most >> 1 : 2u;
-                    const uint64_t donor_m = wave_mask(left >= thr);
-                    uint32_t n = (uint32_t)__popcll(free_m), nd = (uint32_t)__popcll(donor_m);
-                    n = n < nd ? n : nd;
-                    n = n < pool_size - pool_next ? n : pool_size - pool_next;
-                    if (n != 0u) {
-                        const uint32_t rd = __builtin_amdgcn_mbcnt_hi((uint32_t)(donor_m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)donor_m, 0u));
-                        if (lane_of(donor_m) && rd < n) { // give the LAST unstarted sample away
-                            left--;
-                            uint32_t *e = pool + (pool_next + rd) * 4u;
-                            e[0] = key + left * kSampleKeyStep; e[1] = (uint32_t)fx | ((uint32_t)fy << 16); e[2] = rng.inc; // (x, y < 65536: rtr_api.cpp)
-                            e[3] = head;
-                            head = pool_next + rd;
-                        }
-                        __builtin_amdgcn_s_waitcnt(0xC07F); // lgkmcnt(0): the donors' entries are in LDS
-                        __builtin_amdgcn_wave_barrier();
-                        const uint32_t rf = __builtin_amdgcn_mbcnt_hi((uint32_t)(free_m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)free_m, 0u));
-                        if (lane_of(free_m) && rf < n) { // take it: the donor pixel's coordinates and stream
-                            const uint32_t *e = pool + (pool_next + rf) * 4u;
-                            const uint32_t skey = e[0], xy = e[1];
-                            fx = (float)(xy & 0xFFFFu); fy = (float)(xy >> 16); rng.inc = e[2];
-                            cam.start_key(skey, fx, fy, rng, ray);
-                            depth = 0u; chain.reset(); job = pool_next + rf;
-                        }
-                        pool_next += n;
-                    }
-                }
-                if (wave_mask(job != kJobNone || head != kShareNone) == 0ull) break;
-            }
-            if (job != kJobNone) {
-                // ---- trace_ray body (render.rs:32-59): one segment ----
-                Hit h;
-                nseg++;
-                V3 term;
-                const bool was_hit = world_hit<WORLD_LINEAR_SPHERES, NS, 0u, false>(p, ray, h, nullptr, nullptr, lane, sr, lds_spheres, rng);
-                const bool done = shade_segment<true>(p, was_hit, h, ray, rng, lds_mats, chain, depth, term, nullptr, slot_mats);
-                if (done) {
-                    const V3 rad = sample_radiance(p, lds_mats, chain, term); // render.rs:95-97
-                    if (job == kJobOwn) {
-                        acc = add(acc, rad); // render.rs:99
-                        if (left != 0u) { // the next own sample at once (the block at the top of the loop serves the other cases)
-                            cam.start_key(key, fx, fy, rng, ray);
-                            key += kSampleKeyStep; left--; depth = 0u; chain.reset();
-                        } else {
-                            job = kJobNone;
-                        }
-                    } else { // park it for the pixel's lane
-                        uint32_t *e = pool + job * 4u;
-                        e[0] = __float_as_uint(rad.x); e[1] = __float_as_uint(rad.y); e[2] = __float_as_uint(rad.z);
-                        e[3] |= kShareReady; // (after the three words: LDS operations of a wave complete in order)
-                        job = kJobNone;
-                    }
-                }
-            }
-        }
-        ticket_end(ticket, lane, pixel, acc);
-    }
     count_segments(nseg, lane);
 }
 
@@ -2548,11 +2375,6 @@ static const void *render_kernel(const RenderParams &p) {
                                          RTR_FN(k_render<WORLD_LINEAR_GENERIC, 0, 2u, true>)};
         return t[v];
     }
-    if (p.plain_sphere_world && p.lane_sharing) {
-        static const void *const q[6] = {nullptr, RTR_FN(k_render_share<1>), RTR_FN(k_render_share<2>), RTR_FN(k_render_share<3>),
-                                         RTR_FN(k_render_share<4>), RTR_FN(k_render_share<5>)};
-        return q[p.sphere_regs <= 5u ? p.sphere_regs : 0u];
-    }
     if (p.plain_sphere_world) { // Full mode, uniform background, no Mix / Isotropic materials, attenuation chain: shade_segment<PLAIN>
         static const void *const q[9] = {
             nullptr, RTR_FN(k_render<WORLD_LINEAR_SPHERES, 1, 0u, false, true>),
@@ -2654,7 +2476,6 @@ const char *render_kernel_name(const RenderParams &p) {
     if (p.world == WORLD_BVH && p.resumable_walk) return "rtr::k_render_bvh (tree world, resumable walk)";
     if (p.world == WORLD_BVH) return "rtr::k_render<WORLD_BVH> (tree world, wave-synchronous walk)";
     if (p.world == WORLD_LINEAR_GENERIC) return "rtr::k_render<WORLD_LINEAR_GENERIC> (linear world with meshes)";
-    if (p.plain_sphere_world && p.lane_sharing) return "rtr::k_render_share<NS> (linear world, spheres in scalar registers, lanes share samples)";
     return p.sphere_regs ? "rtr::k_render<WORLD_LINEAR_SPHERES, NS> (linear world, spheres in scalar registers)"
                          : "rtr::k_render<WORLD_LINEAR_SPHERES, 0> (linear world, generic sphere loop)";
 }
