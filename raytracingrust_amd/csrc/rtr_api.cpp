@@ -598,7 +598,7 @@ int install_scene(rtr_context *ctx, rtr::FlatScene &flat, std::chrono::steady_cl
 // the reference's rayon fan-out over pixels -- becomes a fan-out over devices.  The scene is replicated; a frame is split
 // by SAMPLES (every rank integrates all pixels for a contiguous share of the samples: the random streams are keyed by the
 // absolute sample index, so the ranks draw exactly the single-GPU numbers and every GPU keeps a full grid of waves) or by
-// TILES (option "multi_split"); the ranks' float4 partial sums are summed onto rank 0 with ONE ncclReduce over xGMI per
+// TILES (option "multi_split"); the ranks' partial sums (three packed floats per pixel) are summed onto rank 0 with ONE ncclReduce over xGMI per
 // frame and rank 0 runs k_resolve (sum / spp, sqrt gamma, RGBA8: render.rs:103-110 must follow the reduce).  One host
 // thread per GPU issues that GPU's work (its own compute and communication streams); partial-sum buffers are double
 // buffered, so frame i's reduce + resolve overlap frame i+1's integrate.
@@ -682,7 +682,7 @@ struct MultiState {
     std::vector<std::unique_ptr<RankWorker>> workers;
     std::vector<hipStream_t> comm_stream;              // per rank, beside the rank context's compute stream
     std::vector<hipEvent_t> ev_integrated[2], ev_reduced[2]; // per buffer, per rank
-    std::vector<void *> d_sum[2];  // per buffer, per rank: float4 partial sums of a frame
+    std::vector<void *> d_sum[2];  // per buffer, per rank: partial sums of a frame, three packed floats per pixel
     void *d_total[2] = {nullptr, nullptr}; // rank 0: the reduced sums
     size_t sum_cap = 0;
     void *d_ptrs = nullptr;        // same_device: the ranks' buffer addresses for the adding kernel
@@ -1071,12 +1071,13 @@ int rtr_set_option(rtr_context *ctx, const char *name, const char *value) {
         ctx->samples_batch = (uint32_t)k;
         return RTR_OK;
     }
-    if (n == "sample_chunks") { // takes effect at the next render
-        if (v == "auto") { ctx->sample_chunks = 0; return RTR_OK; }
+    if (n == "sample_chunks") { // takes effect at the next render (lengths given through "debug_chunk_lengths" go with their count)
+        if (v == "auto") { ctx->sample_chunks = 0; ctx->chunk_lengths.clear(); return RTR_OK; }
         char *end = nullptr;
         const unsigned long k = std::strtoul(v.c_str(), &end, 10);
         if (v.empty() || *end != '\0' || k < 1ul || k > 4096ul) return fail(ctx, RTR_ERR_INVALID_ARGUMENT, "sample_chunks must be \"auto\" or an integer in [1, 4096]");
         ctx->sample_chunks = (int)k;
+        ctx->chunk_lengths.clear();
         return RTR_OK;
     }
     if (n == "debug_chunk_lengths") { // measuring aid: relative chunk lengths, e.g. "24:7:1" (any values give the same frame)
