@@ -698,6 +698,35 @@ def test_sample_chunks_in_the_sharded_paths(gpu_renderer):
     assert np.array_equal(out["1"][0], out["3"][0]) and np.array_equal(out["1"][1], out["3"][1])
 
 
+def test_automatic_chunks_on_a_full_size_frame(gpu_renderer):
+    """What "sample_chunks" = "auto" picks only on large frames (sphere world: pieces in the proportions 24:7:1 from 96 samples
+    on, 7:1 from 28, with the hand-over made of device-scope atomic accesses): a rank's share of the headline frame -- 1920x1080,
+    a sample range that does not start at 0 -- must give the sums of the one-piece launch bit for bit, and so must the frame."""
+    import torch
+
+    r = gpu_renderer
+    w, h = 1920, 1080
+    dev = torch.device("cuda", 0)
+    try:
+        for spp, first, count in ((128, 32, 96), (64, 17, 40)):
+            scene = benchmark_scene(spp)
+            r.upload_scene(scene)
+            sums, frames = [], []
+            for chunks in ("1", "auto", "5"):
+                r.set_option("sample_chunks", chunks)
+                a = torch.zeros((h, w, 3), dtype=torch.float32, device=dev)
+                r.render_samples_device(w, h, 77, first, count, a.data_ptr(), scene=scene)
+                torch.cuda.synchronize()
+                sums.append(a.cpu().numpy().view(np.uint32).copy())
+                rgba = r.render(w, h, seed=77, want_rgba8=True, want_mean=False)[0]
+                frames.append((rgba, r.stats().segments))
+            for k in (1, 2):
+                assert np.array_equal(sums[0], sums[k])
+                assert frames[0][1] == frames[k][1] and np.array_equal(frames[0][0], frames[k][0])
+    finally:
+        r.set_option("sample_chunks", "auto")
+
+
 def test_sample_parallel_kernel_in_batches_and_sample_shards(gpu_renderer):
     """tree_kernel = "samples" / "stream": per-sample radiance goes through device memory and is added per pixel in index order.
     The sample-sharded launches (what a rank of the multi-GPU path runs) must give the same float4 sums as the resumable
