@@ -230,6 +230,7 @@ def roofline_block(prof, prof_status, integrate_ms, alg_bytes, kernel_name, walk
                     "frac": round(gbs / L1_GATHER_PEAK_GBS, 4),
                     "gather_bytes_per_launch": walk["gather_bytes"], "node_steps_per_segment": walk["node_steps_per_segment"],
                     "leaf_tests_per_segment": walk["leaf_tests_per_segment"],
+                    "sky_lookups_per_frame": walk["sky_lookups_per_frame"],
                     "peak_source": "scripts/ubench/gather.hip on this GPU type: per-lane 56-byte record gathers, L1- and L2-resident "
                                    "tables (profiles/r02/evidence/ubench_gather.txt)"})
     if prof is None or integrate_ms <= 0:
@@ -500,7 +501,8 @@ def main():
                 leaf_bytes = tri_share * TRIANGLE_GATHER_BYTES + (1.0 - tri_share) * SPHERE_GATHER_BYTES
                 walk = {"gather_bytes": float(cst.node_steps) * NODE_GATHER_BYTES + float(cst.leaf_tests) * leaf_bytes,
                         "node_steps_per_segment": round(cst.node_steps / max(cst.segments, 1), 2),
-                        "leaf_tests_per_segment": round(cst.leaf_tests / max(cst.segments, 1), 2)}
+                        "leaf_tests_per_segment": round(cst.leaf_tests / max(cst.segments, 1), 2),
+                        "sky_lookups_per_frame": int(cst.sky_lookups)}
         out = {
             "metric": "Mrays/s", "value": round(mrays, 2), "unit": "Mrays/s", "n_gpus": args.gpus if args.native else world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
