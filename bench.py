@@ -489,8 +489,10 @@ def main():
         alg_bytes = b_seg * seg_per_launch + 4.0 * pixels_per_launch
         prof, prof_status = committed_profile(args, W, H, args.gpus if args.native else world)
         walk = None
+        timed_kernel = r.kernel_name()
         if scene.settings.enable_bvh_tree and world == 1 and not args.native and not args.tree_kernel and not args.no_traversal_counters:
             # one more frame of the last timed seed through the counting instantiation of the samples kernel: what the walk gathered
+            # (the same visits whichever tree kernel the timed frames took: every lane walks its ray the same way in all of them)
             r.set_option("traversal_counters", "on")
             r.render_frame_device(W, H, args.seed + args.warmup + args.steps - 1, rgba8.data_ptr(), stream)
             cst = r.stats()
@@ -523,7 +525,7 @@ def main():
                 "upload_ms": round(float(stats.upload_ms), 3),
                 "parity": "unpinned (the reference holds no fixtures and cannot be built here); checked against oracle/",
             },
-            "roofline": roofline_block(prof, prof_status, my_integrate_ms, alg_bytes, r.kernel_name(), walk),
+            "roofline": roofline_block(prof, prof_status, my_integrate_ms, alg_bytes, timed_kernel, walk),
         }
         if not args.no_cpu_baseline and world == 1 and not (args.native and args.gpus > 1):
             rec, o_rgba, o_spp, o_segments = cpu_baseline(scene, W, H, args.cpu_spp, args.seed)
